@@ -1,0 +1,5 @@
+from .datasets import get_dataset, SyntheticImageNet, ImageFolderDataset, IMAGENET_MEAN, IMAGENET_STD
+from .loader import make_iter_dataloader, build_loader, DevicePrefetcher
+
+__all__ = ["get_dataset", "SyntheticImageNet", "ImageFolderDataset", "IMAGENET_MEAN", "IMAGENET_STD",
+           "make_iter_dataloader", "build_loader", "DevicePrefetcher"]

@@ -1,0 +1,89 @@
+"""Loaders: infinite iteration, per-rank sharding and device prefetch.
+
+Upstream wraps its training ``DataLoader`` in ``make_iter_dataloader`` -- an endless
+generator that restarts the loader at the end of each epoch -- and moves every batch to
+the GPU with ``non_blocking=True`` from pinned memory at the top of the step
+(reference ``train_distributed.py:227-249,252,272-273``).
+
+:class:`DevicePrefetcher` additionally issues the host-to-device copy of batch *k+1* on a
+dedicated HIP stream while step *k* computes, so the copy never sits on the critical
+path; the consumer stream waits on an event, not on the host.
+"""
+from __future__ import annotations
+
+from typing import Iterator, Optional, Tuple
+
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from ..parallel.sampler import DistributedShardSampler
+
+
+def make_iter_dataloader(loader: DataLoader, start_epoch: int = 0) -> Iterator:
+    """Endless ``(img, label)`` generator; advances the sampler's epoch at every restart."""
+    epoch = start_epoch
+    while True:
+        sampler = getattr(loader, "sampler", None)
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(epoch)
+        for batch in loader:
+            yield batch
+        epoch += 1
+
+
+def build_loader(dataset: Dataset, batch_size: int, num_workers: int, train: bool, world_size: int, rank: int,
+                 seed: int = 0, pin_memory: bool = True, pad_val: bool = False) -> DataLoader:
+    """Per-rank loader: shuffled + ``drop_last`` shards for training, ordered shards for validation."""
+    sampler = DistributedShardSampler(
+        len(dataset), num_replicas=world_size, rank=rank, shuffle=train, seed=seed,
+        drop_last=train, pad=pad_val if not train else False,
+    )
+    return DataLoader(
+        dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers,
+        pin_memory=pin_memory and torch.cuda.is_available(), drop_last=train,
+        persistent_workers=num_workers > 0,
+    )
+
+
+class DevicePrefetcher:
+    """Wraps a batch iterator; keeps one batch in flight to ``device`` on a copy stream."""
+
+    def __init__(self, it: Iterator, device: torch.device) -> None:
+        self.it = iter(it)
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.stream: Optional[torch.cuda.Stream] = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self._next: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+        self._event = None
+        self._preload()
+
+    def _preload(self) -> None:
+        try:
+            img, label = next(self.it)
+        except StopIteration:
+            self._next = None
+            return
+        if not self.cuda:
+            self._next = (img, label)
+            return
+        with torch.cuda.stream(self.stream):
+            img = img.to(self.device, non_blocking=True)
+            label = label.to(self.device, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record(self.stream)
+        self._next = (img, label)
+
+    def __iter__(self) -> "DevicePrefetcher":
+        return self
+
+    def __next__(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._next is None:
+            raise StopIteration
+        img, label = self._next
+        if self.cuda:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(self._event)
+            img.record_stream(cur)
+            label.record_stream(cur)
+        self._preload()
+        return img, label

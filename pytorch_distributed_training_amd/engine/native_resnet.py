@@ -1,0 +1,381 @@
+"""Native ResNet training engine: an explicit forward / backward program over fused ops.
+
+What upstream does implicitly through ``DistributedDataParallel(model)(img)``,
+``loss.backward()`` and ``optimizer.step()`` (reference ``train_distributed.py:196-198,
+267-278``) -- eager NCHW fp32 modules, autograd, ``SyncBatchNorm`` with two blocking
+collectives per layer, per-parameter gradient tensors copied in and out of DDP buckets --
+is written out here as a static program for one GPU per process:
+
+* activations are NHWC in the compute dtype (bf16 on MI355X), parameters live in flat
+  fp32 buffers (:mod:`.params`) with a bf16 mirror, BatchNorm statistics stay fp32;
+* forward of a conv+BN unit is ``conv (per-channel moments come out of the conv
+  epilogue) -> [SyncBN: ONE all-reduce of 2C floats] -> finalize -> fused
+  scale/shift(+residual)(+ReLU)``;
+* backward is hand-derived: ``fused ReLU-mask + BN reduce -> [SyncBN: ONE all-reduce of
+  2C floats] -> fused BN elementwise -> weight-gradient (accumulates into the flat
+  gradient buffer) -> data-gradient (residual add fused into its epilogue)``.  No
+  autograd graph is recorded;
+* after each layer's gradients are final the bucketed reducer
+  (:mod:`..parallel.reducer`) is told how far the flat gradient buffer is complete, so
+  RCCL all-reduces overlap the rest of backward on a side stream.
+
+The ops come from an op backend (``ops.hip`` on MI355X, ``ops.ref`` on CPU), so the same
+program is exercised by the CPU/gloo tests and checked against the eager model
+(:class:`..models.resnet.ResNet`) with autograd.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from ..models.resnet import BlockSpec, ConvBNSpec, ResNetSpec
+from ..ops import ref as _ref
+from ..parallel.reducer import GradReducer
+from ..utils.profiling import trace_range
+from .params import FlatParams, make_buckets
+
+MASK_NONE, MASK_TENSOR, MASK_RECOMPUTE = _ref.MASK_NONE, _ref.MASK_TENSOR, _ref.MASK_RECOMPUTE
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def backward_param_order(spec: ResNetSpec) -> List[str]:
+    """Parameter keys in the order backward finalises their gradients."""
+    order: List[str] = ["fc.weight", "fc.bias"]
+
+    def unit_keys(u: ConvBNSpec) -> List[str]:
+        return [f"{u.bn}.weight", f"{u.bn}.bias", f"{u.conv}.weight"]
+
+    for b in reversed(spec.blocks):
+        for u in reversed(b.units):
+            order += unit_keys(u)
+        if b.downsample is not None:
+            order += unit_keys(b.downsample)
+    order += unit_keys(spec.stem)
+    return order
+
+
+class _UnitCtx:
+    """Tensors a conv+BN unit keeps from forward for its backward."""
+
+    __slots__ = ("x_in", "y", "scale", "shift", "mean", "invstd", "count")
+
+    def __init__(self) -> None:
+        self.x_in = self.y = self.scale = self.shift = self.mean = self.invstd = None
+        self.count = 0
+
+
+class NativeResNet:
+    def __init__(self, spec: ResNetSpec, device: torch.device, ops, compute_dtype: torch.dtype = torch.bfloat16,
+                 sync_bn: bool = False, group=None, bucket_cap_mb: float = 25.0, first_bucket_mb: float = 1.0,
+                 overlap_comm: bool = True, bn_momentum: float = 0.1, bn_eps: float = 1e-5) -> None:
+        self.spec = spec
+        self.device = torch.device(device)
+        self.ops = ops
+        self.dtype = compute_dtype
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.sync_bn = bool(sync_bn) and self.world > 1
+        self.bn_momentum = bn_momentum
+        self.bn_eps = bn_eps
+        self.training = True
+
+        schema = spec.state_dict_schema()
+        order = backward_param_order(spec)
+        assert sorted(order) == sorted(spec.parameter_keys())
+        self.params = FlatParams([(k, schema[k][0]) for k in order], self.device, compute_dtype)
+        self.buckets = make_buckets(self.params, bucket_cap_mb, first_bucket_mb)
+        self.reducer = GradReducer(self.params.g, self.buckets, group=group, overlap=overlap_comm)
+
+        # BatchNorm running statistics: flat fp32 buffers, one slot per BN in forward order.
+        self.units = spec.conv_bn_units()
+        self._bn_off: Dict[str, Tuple[int, int]] = {}
+        off = 0
+        for u in self.units:
+            self._bn_off[u.bn] = (off, u.cout)
+            off += u.cout
+        self.running_mean = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.running_var = torch.ones(off, dtype=torch.float32, device=self.device)
+        self.num_batches_tracked: Dict[str, int] = {u.bn: 0 for u in self.units}
+
+        self.mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float32, device=self.device)
+        self.std = torch.tensor(IMAGENET_STD, dtype=torch.float32, device=self.device)
+
+        # Data-gradient weight copies [Cin, R, S, Cout] (only for backends that want them).
+        self._needs_wt = bool(getattr(ops, "needs_wt", False))
+        self.wt: Optional[torch.Tensor] = None
+        if self._needs_wt:
+            self.wt = torch.zeros(self.params.total, dtype=compute_dtype, device=self.device)
+        self._stem_w = None
+        self._fc_aux = None
+        self._eval_affine: Optional[Dict[str, Tuple[torch.Tensor, torch.Tensor]]] = None
+        self._ctx: Dict[str, _UnitCtx] = {}
+        self._saved: Dict[str, object] = {}
+        self.refresh_derived_weights()
+
+    # ------------------------------------------------------------------ parameters / state
+    def rm(self, bn: str) -> torch.Tensor:
+        o, c = self._bn_off[bn]
+        return self.running_mean[o:o + c]
+
+    def rv(self, bn: str) -> torch.Tensor:
+        o, c = self._bn_off[bn]
+        return self.running_var[o:o + c]
+
+    def _wt_view(self, key: str) -> Optional[torch.Tensor]:
+        if self.wt is None:
+            return None
+        e = self.params.entries[key]
+        co, r, s, ci = e.shape
+        return self.wt[e.offset:e.offset + e.numel].view(ci, r, s, co)
+
+    def refresh_derived_weights(self) -> None:
+        """Rebuild every weight image derived from the compute mirror (after an optimizer
+        step or a state load): dgrad copies, the packed stem filter, the padded classifier."""
+        P, ops = self.params, self.ops
+        if self._needs_wt:
+            for u in self.units[1:]:
+                key = f"{u.conv}.weight"
+                ops.transpose_weights(P.compute(key), self._wt_view(key))
+        self._stem_w = ops.prepare_stem_weight(P.compute("conv1.weight"))
+        prep_fc = getattr(ops, "prepare_fc", None)
+        self._fc_aux = prep_fc(P.compute("fc.weight")) if prep_fc is not None else None
+        self._eval_affine = None
+
+    def train(self, mode: bool = True) -> "NativeResNet":
+        self.training = mode
+        return self
+
+    def eval(self) -> "NativeResNet":
+        return self.train(False)
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """Model state in the torchvision ResNet schema (fp32, OIHW, no ``module.`` prefix)."""
+        exported = self.params.export("p")
+        out: Dict[str, torch.Tensor] = {}
+        for key, (shape, dtype) in self.spec.state_dict_schema().items():
+            if key in exported:
+                out[key] = exported[key]
+            elif key.endswith("running_mean"):
+                out[key] = self.rm(key[: -len(".running_mean")]).clone()
+            elif key.endswith("running_var"):
+                out[key] = self.rv(key[: -len(".running_var")]).clone()
+            else:
+                bn = key[: -len(".num_batches_tracked")]
+                out[key] = torch.tensor(self.num_batches_tracked[bn], dtype=torch.int64)
+        return out
+
+    def load_state_dict(self, state: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        state = {(k[7:] if k.startswith("module.") else k): v for k, v in state.items()}
+        schema = self.spec.state_dict_schema()
+        if strict:
+            missing = [k for k in schema if k not in state and not k.endswith("num_batches_tracked")]
+            unexpected = [k for k in state if k not in schema]
+            if missing or unexpected:
+                raise KeyError(f"state dict mismatch: missing={missing[:5]} unexpected={unexpected[:5]}")
+        self.params.load_from(state, "p", strict=strict)
+        for u in self.units:
+            if f"{u.bn}.running_mean" in state:
+                self.rm(u.bn).copy_(state[f"{u.bn}.running_mean"].to(torch.float32))
+                self.rv(u.bn).copy_(state[f"{u.bn}.running_var"].to(torch.float32))
+            nbt = state.get(f"{u.bn}.num_batches_tracked")
+            if nbt is not None:
+                self.num_batches_tracked[u.bn] = int(nbt)
+        self.refresh_derived_weights()
+
+    def broadcast_state(self, src: int = 0) -> None:
+        """Initial replica synchronisation: ONE flat broadcast each for parameters and for
+        BN buffers (DDP does this at construction, ``torch/nn/parallel/distributed.py:864-871``)."""
+        if self.world > 1:
+            dist.broadcast(self.params.p, src=src, group=self.group)
+            dist.broadcast(self.params.m, src=src, group=self.group)
+            self.sync_buffers(src)
+            self.params.refresh_compute()
+            self.refresh_derived_weights()
+
+    def sync_buffers(self, src: int = 0) -> None:
+        """Rank ``src``'s running statistics win (what DDP's per-forward buffer broadcast gives
+        upstream without SyncBN).  With SyncBN every rank already holds identical values."""
+        if self.world > 1:
+            dist.broadcast(self.running_mean, src=src, group=self.group)
+            dist.broadcast(self.running_var, src=src, group=self.group)
+            self._eval_affine = None
+
+    # ------------------------------------------------------------------ BN helpers
+    def _bn_train(self, u: ConvBNSpec, ctx: _UnitCtx, moments: torch.Tensor, n_local: int) -> None:
+        P = self.params
+        if self.sync_bn:
+            dist.all_reduce(moments, group=self.group)
+            inv_world, count = 1.0 / self.world, n_local * self.world
+        else:
+            inv_world, count = 1.0, n_local
+        ctx.scale, ctx.shift, ctx.mean, ctx.invstd = self.ops.bn_finalize(
+            moments, inv_world, P.param(f"{u.bn}.weight"), P.param(f"{u.bn}.bias"),
+            self.rm(u.bn), self.rv(u.bn), self.bn_momentum, self.bn_eps, count)
+        ctx.count = count
+        self.num_batches_tracked[u.bn] += 1
+
+    def _bn_backward(self, u: ConvBNSpec, ctx: _UnitCtx, g: torch.Tensor, mask_src, mask_mode: int) -> torch.Tensor:
+        """Gradient w.r.t. the raw conv output; accumulates dgamma / dbeta into the flat buffer."""
+        P, ops = self.params, self.ops
+        sums = ops.bn_bwd_reduce(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, mask_src, mask_mode,
+                                 P.grad(f"{u.bn}.weight"), P.grad(f"{u.bn}.bias"))
+        if self.sync_bn:
+            dist.all_reduce(sums, group=self.group)
+        return ops.bn_bwd_elemt(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, sums, 1.0 / ctx.count,
+                                mask_src, mask_mode)
+
+    def _affine_eval(self, u: ConvBNSpec) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._eval_affine is None:
+            self._eval_affine = {}
+        if u.bn not in self._eval_affine:
+            P = self.params
+            self._eval_affine[u.bn] = self.ops.bn_eval_affine(
+                P.param(f"{u.bn}.weight"), P.param(f"{u.bn}.bias"), self.rm(u.bn), self.rv(u.bn), self.bn_eps)
+        return self._eval_affine[u.bn]
+
+    # ------------------------------------------------------------------ forward
+    def _unit_forward(self, u: ConvBNSpec, x: torch.Tensor, residual: Optional[torch.Tensor], relu: bool,
+                      train: bool) -> torch.Tensor:
+        ops = self.ops
+        w = self.params.compute(f"{u.conv}.weight")
+        y, moments = ops.conv_fprop(x, w, u.ksize, u.ksize, u.stride, u.pad, train)
+        if train:
+            ctx = _UnitCtx()
+            ctx.x_in, ctx.y = x, y
+            self._bn_train(u, ctx, moments, y.numel() // y.shape[-1])
+            self._ctx[u.bn] = ctx
+            scale, shift = ctx.scale, ctx.shift
+        else:
+            scale, shift = self._affine_eval(u)
+        return ops.bn_apply(y, scale, shift, residual, relu)
+
+    def _block_forward(self, b: BlockSpec, x: torch.Tensor, train: bool) -> torch.Tensor:
+        identity = x
+        if b.downsample is not None:
+            identity = self._unit_forward(b.downsample, x, None, False, train)
+        out = x
+        last = len(b.units) - 1
+        for i, u in enumerate(b.units):
+            if i < last:
+                out = self._unit_forward(u, out, None, True, train)
+            else:
+                out = self._unit_forward(u, out, identity, True, train)
+        if train:
+            self._saved[b.name] = out
+        return out
+
+    def forward(self, img: torch.Tensor, train: Optional[bool] = None) -> torch.Tensor:
+        """Logits ``[B, num_classes]`` for a loader batch (float NCHW or uint8 NHWC)."""
+        train = self.training if train is None else train
+        ops = self.ops
+        self._ctx.clear()
+        self._saved.clear()
+        with trace_range("forward"):
+            x0 = ops.input_transform(img, self.mean, self.std, self.dtype)
+            stem = self.spec.stem
+            y, moments = ops.stem_fprop(x0, self._stem_w, train)
+            if train:
+                ctx = _UnitCtx()
+                ctx.x_in, ctx.y = x0, y
+                self._bn_train(stem, ctx, moments, y.numel() // y.shape[-1])
+                self._ctx[stem.bn] = ctx
+                scale, shift = ctx.scale, ctx.shift
+            else:
+                scale, shift = self._affine_eval(stem)
+            a = ops.bn_apply(y, scale, shift, None, True)
+            x, idx = ops.maxpool_fwd(a)
+            if train:
+                self._saved["stem_shape"] = tuple(a.shape)
+                self._saved["pool_idx"] = idx
+            del a
+            for b in self.spec.blocks:
+                x = self._block_forward(b, x, train)
+            pooled = ops.avgpool_fwd(x)
+            if train:
+                self._saved["final_hw"] = (x.shape[1], x.shape[2])
+                self._saved["pooled"] = pooled
+            P = self.params
+            logits = ops.linear_fwd(pooled, P.compute("fc.weight"), P.param("fc.bias"))
+        return logits
+
+    # ------------------------------------------------------------------ backward
+    def _block_backward(self, b: BlockSpec, g: torch.Tensor) -> torch.Tensor:
+        """``g``: gradient w.r.t. the block output (after its ReLU).  Returns d(block input)."""
+        P, ops, red = self.params, self.ops, self.reducer
+        out = self._saved.pop(b.name)
+        last = len(b.units) - 1
+        x_block = self._ctx[b.units[0].bn].x_in
+        cur = g
+        dy_first = None
+        for i in range(last, -1, -1):
+            u = b.units[i]
+            ctx = self._ctx.pop(u.bn)
+            if i == last:
+                dy = self._bn_backward(u, ctx, cur, out, MASK_TENSOR)
+            else:
+                dy = self._bn_backward(u, ctx, cur, None, MASK_RECOMPUTE)
+            key = f"{u.conv}.weight"
+            ops.conv_wgrad(ctx.x_in, dy, u.ksize, u.ksize, u.stride, u.pad, P.grad(key))
+            red.mark_ready(P.end_offset(key))
+            if i > 0:
+                cur = ops.conv_dgrad(dy, P.compute(key), self._wt_view(key), tuple(ctx.x_in.shape),
+                                     u.ksize, u.ksize, u.stride, u.pad)
+            else:
+                dy_first = dy
+        u0 = b.units[0]
+        key0 = f"{u0.conv}.weight"
+        if b.downsample is not None:
+            d = b.downsample
+            ctx = self._ctx.pop(d.bn)
+            dyd = self._bn_backward(d, ctx, g, out, MASK_TENSOR)
+            keyd = f"{d.conv}.weight"
+            ops.conv_wgrad(x_block, dyd, d.ksize, d.ksize, d.stride, d.pad, P.grad(keyd))
+            red.mark_ready(P.end_offset(keyd))
+            dx_ds = ops.conv_dgrad(dyd, P.compute(keyd), self._wt_view(keyd), tuple(x_block.shape),
+                                   d.ksize, d.ksize, d.stride, d.pad)
+            dx = ops.conv_dgrad(dy_first, P.compute(key0), self._wt_view(key0), tuple(x_block.shape),
+                                u0.ksize, u0.ksize, u0.stride, u0.pad, addend=dx_ds)
+        else:
+            dx = ops.conv_dgrad(dy_first, P.compute(key0), self._wt_view(key0), tuple(x_block.shape),
+                                u0.ksize, u0.ksize, u0.stride, u0.pad, addend=g, mask_src=out)
+        return dx
+
+    def backward(self, dlogits: torch.Tensor) -> None:
+        """Back-propagate ``dlogits``; gradients accumulate into the flat gradient buffer."""
+        P, ops, red = self.params, self.ops, self.reducer
+        red.begin_step()
+        with trace_range("backward"):
+            pooled = self._saved.pop("pooled")
+            dpooled = ops.linear_bwd(pooled, dlogits, P.compute("fc.weight"), self._fc_aux,
+                                     P.grad("fc.weight"), P.grad("fc.bias"))
+            red.mark_ready(P.end_offset("fc.bias"))
+            H, W = self._saved.pop("final_hw")
+            g = ops.avgpool_bwd(dpooled, H, W)
+            for b in reversed(self.spec.blocks):
+                g = self._block_backward(b, g)
+            stem = self.spec.stem
+            da = ops.maxpool_bwd(g, self._saved.pop("pool_idx"), self._saved.pop("stem_shape"))
+            ctx = self._ctx.pop(stem.bn)
+            dy = self._bn_backward(stem, ctx, da, None, MASK_RECOMPUTE)
+            ops.stem_wgrad(ctx.x_in, dy, P.grad("conv1.weight"))
+            red.mark_ready(P.end_offset("conv1.weight"))
+        with trace_range("allreduce_wait"):
+            red.finish()
+
+    # ------------------------------------------------------------------ steps
+    def forward_backward(self, img: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+        """One forward + backward; returns the local mean loss (0-dim fp32 device tensor)."""
+        logits = self.forward(img, train=True)
+        loss, dlogits = self.ops.softmax_ce(logits, label, 1.0)
+        self.backward(dlogits)
+        return loss
+
+    @torch.no_grad()
+    def eval_step(self, img: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+        """``[loss_sum, correct@1, correct@5, n]`` for a validation batch."""
+        logits = self.forward(img, train=False)
+        return self.ops.ce_metrics(logits, label)

@@ -1,0 +1,290 @@
+"""Pure-PyTorch fp32 reference implementation of every engine op.
+
+This backend has two jobs: it is the numerical oracle the HIP kernels are tested
+against (same signatures, same tensor layouts), and it is what the engine runs on when
+there is no GPU (CPU / gloo plumbing tests).  Every function up-casts its inputs to fp32,
+computes with stock ``torch`` ops and rounds the result to the activation dtype.
+
+Layouts: activations are NHWC ``[B, H, W, C]`` contiguous; convolution weights are OHWI
+``[Cout, R, S, Cin]``; per-channel vectors are fp32.
+
+The ops correspond to the kernels PyTorch dispatches implicitly for the upstream trainer's
+``model(img)`` / ``loss.backward()`` / ``optimizer.step()`` (reference
+``train_distributed.py:274-277``): convolution forward / data-gradient / weight-gradient,
+(Sync)BatchNorm statistics / apply / backward-reduce / backward-elementwise
+(``torch/nn/modules/_functions.py:39-179``), max/avg pooling, the classifier GEMM,
+softmax cross-entropy, SGD with momentum (``torch/optim/sgd.py:322-367``) and top-k.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+name = "ref"
+
+MASK_NONE = 0       # dy = g
+MASK_TENSOR = 1     # dy = g * (mask_src > 0)
+MASK_RECOMPUTE = 2  # dy = g * (y * scale + shift > 0)
+
+
+def _nchw(x: torch.Tensor) -> torch.Tensor:
+    return x.permute(0, 3, 1, 2)
+
+
+def _nhwc(x: torch.Tensor) -> torch.Tensor:
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _w_oihw(w: torch.Tensor) -> torch.Tensor:
+    return w.permute(0, 3, 1, 2)
+
+
+def channel_moments(y32: torch.Tensor) -> torch.Tensor:
+    """``[2, C]``: per-channel ``E[y]`` and ``E[y^2]`` over all leading dims.
+
+    The second moment is formed as ``var + mean^2`` from a centred variance, so the only
+    cancellation left is the final ``E[y^2] - mean^2`` in :func:`bn_finalize`.  Moments (rather
+    than mean/variance) are what ranks exchange for SyncBatchNorm: with equal per-rank counts
+    the global moments are the plain average of the local ones, i.e. ONE sum all-reduce.
+    """
+    flat = y32.reshape(-1, y32.shape[-1])
+    var, mean = torch.var_mean(flat, dim=0, unbiased=False)
+    return torch.stack([mean, var + mean * mean])
+
+
+# ---------------------------------------------------------------------------- input
+def input_transform(img: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Loader batch -> stem input.
+
+    ``img`` is either float NCHW, already normalised (the upstream loader contract,
+    reference ``train_distributed.py:272``), or uint8 NHWC raw pixels, normalised here
+    with ``(x/255 - mean) / std``.  Returns NHWC ``[B, H, W, 3]`` in ``dtype``.
+    """
+    if img.dtype == torch.uint8:
+        x = img.float().div_(255.0)
+        x = (x - mean.view(1, 1, 1, 3)) / std.view(1, 1, 1, 3)
+        return x.to(dtype).contiguous()
+    return _nhwc(img.float()).to(dtype)
+
+
+def prepare_stem_weight(w: torch.Tensor) -> torch.Tensor:
+    """Compute-side stem weights from the ``[64, 7, 7, 3]`` compute-dtype view (identity here)."""
+    return w
+
+
+def stem_fprop(x0: torch.Tensor, w: torch.Tensor, want_stats: bool):
+    return conv_fprop(x0, w, 7, 7, 2, 3, want_stats)
+
+
+def stem_wgrad(x0: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) -> None:
+    conv_wgrad(x0, dy, 7, 7, 2, 3, dw)
+
+
+# ---------------------------------------------------------------------------- convolution
+def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pad: int,
+               want_stats: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    y32 = F.conv2d(_nchw(x.float()), _w_oihw(w.float()), None, stride, pad)
+    y32 = _nhwc(y32)
+    stats = channel_moments(y32) if want_stats else None
+    return y32.to(x.dtype), stats
+
+
+def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: Optional[torch.Tensor], in_shape, R: int, S: int,
+               stride: int, pad: int, addend: Optional[torch.Tensor] = None,
+               mask_src: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``dx = conv_transpose(dy, w) [+ addend * (mask_src > 0)]`` ; ``in_shape = (B, Hi, Wi, Ci)``."""
+    B, Hi, Wi, Ci = in_shape
+    dx = torch.nn.grad.conv2d_input((B, Ci, Hi, Wi), _w_oihw(w.float()), _nchw(dy.float()), stride, pad)
+    dx = _nhwc(dx)
+    if addend is not None:
+        a = addend.float()
+        if mask_src is not None:
+            a = a * (mask_src.float() > 0)
+        dx = dx + a
+    return dx.to(dy.dtype)
+
+
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, R: int, S: int, stride: int, pad: int, dw: torch.Tensor) -> None:
+    """``dw[Cout, R, S, Cin] += x (*) dy`` (fp32 accumulate into the flat gradient buffer)."""
+    Co, Ci = dy.shape[-1], x.shape[-1]
+    g = torch.nn.grad.conv2d_weight(_nchw(x.float()), (Co, Ci, R, S), _nchw(dy.float()), stride, pad)
+    dw.add_(g.permute(0, 2, 3, 1))
+
+
+def transpose_weights(w: torch.Tensor, wt: Optional[torch.Tensor]) -> None:
+    """Fill the data-gradient weight copy ``wt[Cin, R, S, Cout]`` (unused by this backend)."""
+    if wt is not None:
+        wt.copy_(w.permute(3, 1, 2, 0))
+
+
+# ---------------------------------------------------------------------------- batch norm
+def bn_stats(y: torch.Tensor) -> torch.Tensor:
+    """Stand-alone per-channel moments ``[E[y], E[y^2]]`` of an NHWC tensor."""
+    return channel_moments(y.float())
+
+
+def bn_finalize(moments: torch.Tensor, inv_world: float, gamma: torch.Tensor, beta: torch.Tensor,
+                running_mean: torch.Tensor, running_var: torch.Tensor, momentum: float, eps: float, count: int):
+    """Summed moments -> ``(scale, shift, mean, invstd)``; updates running stats in place.
+
+    ``moments`` is the (all-reduced) SUM over ranks of the local ``[E[y], E[y^2]]`` and
+    ``inv_world = 1 / world_size`` turns it into the global moments.  ``scale = gamma *
+    invstd``, ``shift = beta - mean * scale``.  The running variance uses the unbiased
+    estimate with the GLOBAL element count ``count``, as ``SyncBatchNorm`` does
+    (``torch/nn/modules/_functions.py:106-115``).
+    """
+    mean = moments[0] * inv_world
+    var = (moments[1] * inv_world - mean * mean).clamp_min(0.0)
+    invstd = torch.rsqrt(var + eps)
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    unbiased = var * (count / max(count - 1, 1))
+    running_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+    running_var.mul_(1.0 - momentum).add_(unbiased, alpha=momentum)
+    return scale, shift, mean, invstd
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps: float):
+    invstd = torch.rsqrt(running_var + eps)
+    scale = gamma * invstd
+    return scale, beta - running_mean * scale
+
+
+def bn_apply(y: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, residual: Optional[torch.Tensor],
+             relu: bool) -> torch.Tensor:
+    out = y.float() * scale + shift
+    if residual is not None:
+        out = out + residual.float()
+    if relu:
+        out = torch.relu(out)
+    return out.to(y.dtype)
+
+
+def _masked(g, y32, scale, shift, mask_src, mask_mode):
+    dy = g.float()
+    if mask_mode == MASK_TENSOR:
+        dy = dy * (mask_src.float() > 0)
+    elif mask_mode == MASK_RECOMPUTE:
+        dy = dy * ((y32 * scale + shift) > 0)
+    return dy
+
+
+def bn_bwd_reduce(g, y, mean, invstd, scale, shift, mask_src, mask_mode: int,
+                  dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``[2, C]``: local ``sum(dy)`` and ``sum(dy * xhat)`` with ``xhat = (y - mean) * invstd``.
+
+    When given, ``dbeta += sum(dy)`` and ``dgamma += sum(dy * xhat)`` (the LOCAL sums are the
+    parameter gradients; the bucketed all-reduce averages them over ranks later).
+    """
+    y32 = y.float()
+    dy = _masked(g, y32, scale, shift, mask_src, mask_mode)
+    xhat = (y32 - mean) * invstd
+    C = y.shape[-1]
+    sums = torch.stack([dy.reshape(-1, C).sum(0), (dy * xhat).reshape(-1, C).sum(0)])
+    if dbeta is not None:
+        dbeta.add_(sums[0])
+    if dgamma is not None:
+        dgamma.add_(sums[1])
+    return sums
+
+
+def bn_bwd_elemt(g, y, mean, invstd, scale, shift, sums, inv_count: float, mask_src, mask_mode: int) -> torch.Tensor:
+    """``dx = (dy - s0 - xhat * s1) * scale`` with ``[s0, s1] = sums * inv_count``.
+
+    ``sums`` are the (all-reduced) global sums from :func:`bn_bwd_reduce` and ``inv_count`` is
+    one over the GLOBAL number of elements per channel
+    (``torch/nn/modules/_functions.py:170-179``).
+    """
+    y32 = y.float()
+    dy = _masked(g, y32, scale, shift, mask_src, mask_mode)
+    xhat = (y32 - mean) * invstd
+    dx = (dy - sums[0] * inv_count - xhat * (sums[1] * inv_count)) * scale
+    return dx.to(y.dtype)
+
+
+# ---------------------------------------------------------------------------- pooling
+def maxpool_fwd(x: torch.Tensor):
+    """3x3 / stride 2 / pad 1 max pooling; returns ``(out, idx)`` with an opaque index tensor."""
+    out, idx = F.max_pool2d(_nchw(x.float()), 3, 2, 1, return_indices=True)
+    return _nhwc(out).to(x.dtype), idx
+
+
+def maxpool_bwd(dout: torch.Tensor, idx: torch.Tensor, in_shape) -> torch.Tensor:
+    B, H, W, C = in_shape
+    # Overlapping 3x3/s2 windows can select the same input element twice and the gradient
+    # must then be the SUM of both, so scatter-add (max_unpool2d would overwrite).
+    dx = torch.zeros(B, C, H * W, dtype=torch.float32, device=dout.device)
+    dx.scatter_add_(2, idx.reshape(B, C, -1), _nchw(dout.float()).reshape(B, C, -1))
+    return _nhwc(dx.view(B, C, H, W)).to(dout.dtype)
+
+
+def avgpool_fwd(x: torch.Tensor) -> torch.Tensor:
+    return x.float().mean(dim=(1, 2)).to(x.dtype)
+
+
+def avgpool_bwd(dp: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    B, C = dp.shape
+    return (dp.float() / (H * W)).view(B, 1, 1, C).expand(B, H, W, C).contiguous().to(dp.dtype)
+
+
+# ---------------------------------------------------------------------------- classifier + loss
+def linear_fwd(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    return (a.float() @ w.float().t() + bias).to(a.dtype)
+
+
+def linear_bwd(a, dlogits, w, wt, dw: torch.Tensor, dbias: torch.Tensor) -> torch.Tensor:
+    d32 = dlogits.float()
+    dw.add_(d32.t() @ a.float())
+    dbias.add_(d32.sum(0))
+    return (d32 @ w.float()).to(a.dtype)
+
+
+def softmax_ce(logits: torch.Tensor, labels: torch.Tensor, grad_scale: float = 1.0):
+    """Mean cross-entropy and its gradient ``(softmax - onehot) * grad_scale / B`` in one pass."""
+    l32 = logits.float()
+    logp = torch.log_softmax(l32, dim=1)
+    B = l32.shape[0]
+    loss = -logp.gather(1, labels.view(-1, 1).long()).mean()
+    d = torch.exp(logp)
+    d.scatter_add_(1, labels.view(-1, 1).long(), torch.full((B, 1), -1.0, device=d.device))
+    return loss, (d * (grad_scale / B)).to(logits.dtype)
+
+
+def ce_metrics(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """``[loss_sum, correct@1, correct@5, n]`` (fp32) for a validation batch."""
+    l32 = logits.float()
+    lab = labels.view(-1, 1).long()
+    logp = torch.log_softmax(l32, dim=1)
+    loss_sum = -logp.gather(1, lab).sum()
+    rank = (l32 > l32.gather(1, lab)).sum(dim=1)
+    n = torch.tensor(float(l32.shape[0]), device=l32.device)
+    return torch.stack([loss_sum, (rank < 1).sum().float(), (rank < 5).sum().float(), n])
+
+
+# ---------------------------------------------------------------------------- optimizer
+def sgd_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, pc: Optional[torch.Tensor], lr: float,
+             momentum: float, weight_decay: float, grad_scale: float, nesterov: bool = False,
+             dampening: float = 0.0, first_step: bool = False) -> None:
+    """Flat SGD: ``g = g*grad_scale + wd*p; m = mu*m + (1-damp)*g; p -= lr*(m | g+mu*m)``.
+
+    Zeroes ``g`` afterwards (weight-gradient kernels accumulate into it) and refreshes the
+    compute-dtype mirror ``pc`` when it is a separate buffer.  On the first step the
+    momentum buffer is initialised to the gradient, like ``torch.optim.SGD``.
+    """
+    grad = g * grad_scale
+    if weight_decay != 0.0:
+        grad = grad + weight_decay * p
+    if momentum != 0.0:
+        if first_step:
+            m.copy_(grad)
+        else:
+            m.mul_(momentum).add_(grad, alpha=1.0 - dampening)
+        step = grad + momentum * m if nesterov else m
+    else:
+        step = grad
+    p.add_(step, alpha=-lr)
+    g.zero_()
+    if pc is not None and pc.data_ptr() != p.data_ptr():
+        pc.copy_(p)

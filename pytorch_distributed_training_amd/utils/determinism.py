@@ -1,0 +1,55 @@
+"""Seeding helpers.
+
+Upstream calls ``make_deterministic(seed)`` once in the launcher and once more in every
+worker with the *same* seed, so that all ranks build identical initial weights
+(reference ``train_distributed.py:51-53,141-142``).
+"""
+from __future__ import annotations
+
+import os
+import random
+
+import numpy as np
+import torch
+
+
+def make_deterministic(seed: int, strict: bool = False) -> None:
+    """Seed python, numpy and torch (CPU and every visible GPU) RNGs.
+
+    ``strict=True`` additionally asks torch for deterministic algorithms; the hand-written
+    weight-gradient kernels accumulate with float atomics, so bitwise reproducibility of
+    a GPU run is not promised either way (upstream is not bit-deterministic either: it
+    enables cudnn autotuning right after seeding, ``train_distributed.py:54``).
+    """
+    seed = int(seed)
+    os.environ.setdefault("PYTHONHASHSEED", str(seed))
+    random.seed(seed)
+    np.random.seed(seed % (2 ** 32))
+    torch.manual_seed(seed)
+    if torch.cuda.device_count() > 0 and torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    if strict:
+        torch.use_deterministic_algorithms(True, warn_only=True)
+
+
+def rng_state() -> dict:
+    """Snapshot of all RNG states (stored in training checkpoints)."""
+    state = {
+        "python": random.getstate(),
+        "numpy": np.random.get_state(),
+        "torch": torch.get_rng_state(),
+    }
+    if torch.cuda.device_count() > 0 and torch.cuda.is_available():
+        state["cuda"] = torch.cuda.get_rng_state_all()
+    return state
+
+
+def set_rng_state(state: dict) -> None:
+    random.setstate(state["python"])
+    np.random.set_state(state["numpy"])
+    torch.set_rng_state(state["torch"])
+    if "cuda" in state and torch.cuda.device_count() > 0 and torch.cuda.is_available():
+        try:
+            torch.cuda.set_rng_state_all(state["cuda"])
+        except Exception:  # different GPU count on resume: keep the fresh states
+            pass
