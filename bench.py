@@ -1,0 +1,166 @@
+"""Headline benchmark: ResNet-50 bf16 training throughput (images/s, whole job) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+For N > 1 launch one rank per GPU, e.g.
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+--master-port P bench.py --gpus N --steps K --warmup W``; RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* are read from the environment and collectives go over RCCL.
+
+A step is the full training iteration of the trainer: host-to-device copy of a synthetic
+uint8 ImageNet-shaped batch (prefetched on a copy stream), fused normalise/layout kernel,
+forward, loss, backward with SyncBatchNorm (N > 1) and bucketed gradient all-reduce
+overlapped on a side stream, fused SGD step.  Weak scaling: the per-GPU batch is fixed.
+W un-timed warm-up steps, then exactly K timed steps bracketed by barrier +
+``torch.cuda.synchronize()``; the time is the MAX over ranks; rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from pytorch_distributed_training_amd.config import validate_cfg  # noqa: E402
+from pytorch_distributed_training_amd.data.loader import DevicePrefetcher  # noqa: E402
+from pytorch_distributed_training_amd.engine.engines import build_engine  # noqa: E402
+from pytorch_distributed_training_amd.parallel import dist_env  # noqa: E402
+
+
+def synthetic_batches(batch: int, image_size: int, n_classes: int, fmt: str, device: torch.device, mode: str,
+                      pool: int = 4, seed: int = 0):
+    """Endless generator of (img, label) batches with ImageNet's shapes.
+
+    ``mode='h2d'``: batches live in pinned host memory and are copied every step (what a real
+    loader delivers); ``mode='device'``: batches are resident on the GPU.
+    """
+    g = torch.Generator().manual_seed(seed)
+    imgs, labels = [], []
+    for _ in range(pool):
+        if fmt == "uint8_nhwc":
+            img = torch.randint(0, 256, (batch, image_size, image_size, 3), generator=g, dtype=torch.uint8)
+        else:
+            img = torch.randn(batch, 3, image_size, image_size, generator=g)
+        lab = torch.randint(0, n_classes, (batch,), generator=g, dtype=torch.int64)
+        if mode == "device":
+            img, lab = img.to(device), lab.to(device)
+        elif device.type == "cuda":
+            img, lab = img.pin_memory(), lab.pin_memory()
+        imgs.append(img)
+        labels.append(lab)
+    i = 0
+    while True:
+        yield imgs[i % pool], labels[i % pool]
+        i += 1
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", type=str, default="ResNet50")
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch size")
+    ap.add_argument("--engine", type=str, default="native", choices=("native", "torch"))
+    ap.add_argument("--input-format", type=str, default="uint8_nhwc", choices=("uint8_nhwc", "float_nchw"))
+    ap.add_argument("--data-mode", type=str, default="h2d", choices=("h2d", "device"))
+    ap.add_argument("--sync-bn", type=int, default=1, help="SyncBatchNorm when more than one GPU")
+    ap.add_argument("--bucket-cap-mb", type=float, default=25.0)
+    ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--backend", type=str, default="nccl")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 or args.gpus > 1:
+        if world != args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU with "
+                  "torch.distributed.run", file=sys.stderr)
+            return 2
+        info = dist_env.init_from_env(args.backend)
+    else:
+        info = dist_env.init_distributed(args.backend, None, 1, 0, 0, 1)
+    device = info.device
+    if device.type != "cuda":
+        print("bench.py: no GPU visible", file=sys.stderr)
+        return 2
+
+    cfg = validate_cfg({
+        "dataset": {"name": "synthetic", "n_classes": 1000, "image_size": args.image_size,
+                    "input_format": args.input_format},
+        "training": {
+            "optimizer": {"name": "SGD", "lr": 0.1, "weight_decay": 1.0e-4, "momentum": 0.9},
+            "lr_schedule": {"name": "multi_step", "milestones": [150000, 300000], "gamma": 0.1},
+            "train_iters": args.steps + args.warmup, "batch_size": args.batch * max(args.gpus, 1),
+            "per_gpu_batch_size": args.batch, "sync_bn": bool(args.sync_bn), "precision": "bf16",
+            "bucket_cap_mb": args.bucket_cap_mb, "engine": args.engine,
+        },
+        "model": {"name": args.model},
+    })
+    torch.manual_seed(1029)
+    engine = build_engine(cfg, device)
+    source = synthetic_batches(args.batch, args.image_size, 1000, args.input_format, device, args.data_mode,
+                               seed=info.rank)
+    batches = DevicePrefetcher(source, device) if args.data_mode == "h2d" else source
+
+    def step():
+        img, label = next(batches)
+        return engine.train_step(img, label)
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = step()
+    if info.distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if info.distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if info.distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    final_loss = float(loss) if loss is not None else float("nan")
+    global_batch = args.batch * info.world_size
+    value = global_batch * args.steps / elapsed
+    if info.rank == 0:
+        print(json.dumps({
+            "metric": f"train images/sec (whole node) {args.model} bf16",
+            "value": round(value, 2),
+            "unit": "images/s",
+            "n_gpus": info.world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": f"synthetic ImageNet-shaped ({args.input_format}, {args.data_mode}), random-init weights",
+            "config": {
+                "model": args.model, "global_batch": global_batch, "per_gpu_batch": args.batch,
+                "image_size": args.image_size, "seq_len": None,
+                "parallelism": f"dp{info.world_size}" + ("+syncbn" if (args.sync_bn and info.world_size > 1) else ""),
+                "engine": args.engine, "optimizer": "SGD momentum 0.9 wd 1e-4", "final_loss": round(final_loss, 4),
+                "peak_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
+            },
+        }), flush=True)
+    if info.distributed:
+        dist_env.shutdown()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -242,7 +242,7 @@ class NativeResNet:
                       train: bool) -> torch.Tensor:
         ops = self.ops
         w = self.params.compute(f"{u.conv}.weight")
-        y, moments = ops.conv_fprop(x, w, u.ksize, u.ksize, u.stride, u.pad, train)
+        y, moments = ops.conv_fprop(x, w, u.ksize, u.ksize, u.stride, u.pad, self.rm(u.bn) if train else None)
         if train:
             ctx = _UnitCtx()
             ctx.x_in, ctx.y = x, y
@@ -277,7 +277,7 @@ class NativeResNet:
         with trace_range("forward"):
             x0 = ops.input_transform(img, self.mean, self.std, self.dtype)
             stem = self.spec.stem
-            y, moments = ops.stem_fprop(x0, self._stem_w, train)
+            y, moments = ops.stem_fprop(x0, self._stem_w, self.rm(stem.bn) if train else None)
             if train:
                 ctx = _UnitCtx()
                 ctx.x_in, ctx.y = x0, y

@@ -1,0 +1,51 @@
+// Shared device helpers for the gfx950 (MI355X, CDNA4) kernels.
+//
+// Conventions used by every kernel in this directory:
+//   * wavefront = 64 lanes, blocks are multiples of 64 threads (256 unless noted);
+//   * activations are NHWC bf16, accessed 16 bytes (8 channels) per lane;
+//   * per-channel vectors and all accumulations are fp32;
+//   * every launcher takes raw device pointers plus a hipStream_t and returns a hipError_t
+//     cast to int (0 = success), so the library has a plain C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define PDT_API extern "C" __attribute__((visibility("default")))
+
+enum { MASK_NONE = 0, MASK_TENSOR = 1, MASK_RECOMPUTE = 2 };
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
+
+__device__ __forceinline__ bf16x8 ld_bf16x8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void st_bf16x8(bf16* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
+
+__device__ __forceinline__ bf16x8 zero_bf16x8() {
+    bf16x8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (bf16)0.0f;
+    return z;
+}
+
+// Sum over the 64 lanes of a wave (all lanes get the result).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+static inline int pdt_launch_status() { return (int)hipGetLastError(); }
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,255 @@
+// Weight-gradient convolution for gfx950 (MI355X), NHWC bf16 activations, fp32 output:
+//
+//   dw[n][widx(t)*Ci + c] += sum_{m in split} dy[m][n] * in[pix(m, t)][c]
+//
+// i.e. for every filter tap t a GEMM  dW_t[Cout x Cin] = dY^T[Cout x P] . X_t[P x Cin]  whose
+// reduction runs over the P = B*Ho*Wo output pixels.  Both operands are stored pixel-major
+// (the reduction index is the slow one), which is the wrong way round for the MFMA operand
+// layout (each lane wants 8 consecutive k for one row/column).  The tiles are therefore staged
+// row-major [pixel][channel] in LDS and read with the gfx950 transposing LDS load
+// ds_read_b64_tr_b16: one 16-lane group fetches 4 pixels x 16 channels and gets them delivered
+// channel-major.  The pixel <-> MFMA-k assignment is free as long as A and B agree, so lane
+// group g takes pixels {4g..4g+3} and {16+4g..16+4g+3} of each 32-pixel step; with the row
+// stride padded to (channels*2 + 32) bytes the 8 rows a 32-lane half touches fall into 8
+// distinct 32-byte bank ranges: conflict-free.
+//
+// The reduction is huge for the early layers (B*56*56) and the output tiny, so parallelism
+// comes from split-K: each block reduces one slice of pixels for one (Cout tile, Cin tile,
+// tap) and adds its fp32 tile into the flat gradient buffer with float atomics (the buffer
+// is zeroed by the fused optimizer kernel).  Workgroups that share the same dY slice are
+// adjacent after the XCD remap, so re-reads of dY across taps / Cin tiles hit in L2.
+#include "common.h"
+
+#define MAX_TAPS 52
+#define BKP 64   // pixels per K step
+
+struct WgradParams {
+    const bf16* dy;
+    const bf16* in;
+    float* dw;
+    long long M;
+    int Hi, Wi, pix_stride, Ci;
+    int Hg, Wg, IS;
+    int N, ldy, wrow, T;
+    int splitk;
+    long long rows_per_split;
+    signed char offy[MAX_TAPS];
+    signed char offx[MAX_TAPS];
+    unsigned short widx[MAX_TAPS];
+};
+
+__device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char* base0, const unsigned char* base1) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base1));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo;
+    u.s.b = hi;
+    return u.v;
+}
+
+template <int BMO, int BNC, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+    constexpr int RSA = (BMO + 16) * 2;       // LDS row stride (bytes), dY tile
+    constexpr int RSB = (BNC + 16) * 2;       // LDS row stride (bytes), X tile
+    constexpr int A_BYTES = BKP * RSA, B_BYTES = BKP * RSB;
+    constexpr int AV = BMO / 8, BV = BNC / 8; // 16-byte vectors per tile row
+    constexpr int A_RPP = 256 / AV, B_RPP = 256 / BV;
+    constexpr int A_IT = (BKP + A_RPP - 1) / A_RPP, B_IT = (BKP + B_RPP - 1) / B_RPP;
+    constexpr int WTM = BMO / WM, WTN = BNC / WN;
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+    static_assert(A_RPP <= BKP ? BKP % A_RPP == 0 : true, "");
+    static_assert(B_RPP <= BKP ? BKP % B_RPP == 0 : true, "");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int n_ct = (p.N + BMO - 1) / BMO;
+    const int n_cin = (p.Ci + BNC - 1) / BNC;
+    const int inner = p.T * n_cin;
+    const int nwg = p.splitk * n_ct * inner;
+    int wgid;
+    {
+        int orig = blockIdx.x;
+        int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int in_idx = wgid % inner;
+    const int rest = wgid / inner;
+    const int ct = rest % n_ct;
+    const int split = rest / n_ct;
+    const int tap = in_idx / n_cin;
+    const int cin_tile = in_idx % n_cin;
+    const int co0 = ct * BMO, ci0 = cin_tile * BNC;
+    const int oy = p.offy[tap], ox = p.offx[tap];
+
+    const long long r_begin = (long long)split * p.rows_per_split;
+    long long r_end = r_begin + p.rows_per_split;
+    if (r_end > p.M) r_end = p.M;
+    const int nk = r_begin < r_end ? (int)((r_end - r_begin + BKP - 1) / BKP) : 0;
+
+    const int a_cv = tid % AV, a_row = tid / AV;
+    const int b_cv = tid % BV, b_row = tid / BV;
+    const bool a_col_ok = co0 + a_cv * 8 < p.N;          // N is checked at 8-granularity (ldy padded)
+    const bool b_col_ok = ci0 + b_cv * 8 < p.Ci;
+    const int HgWg = p.Hg * p.Wg;
+
+    bf16x8 a_reg[A_IT], b_reg[B_IT];
+    auto load_tiles = [&](long long r0) {
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            int row = a_row + j * A_RPP;
+            long long m = r0 + row;
+            if (row < BKP && m < r_end && a_col_ok) a_reg[j] = ld_bf16x8(p.dy + m * p.ldy + co0 + a_cv * 8);
+            else a_reg[j] = zero_bf16x8();
+        }
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            int row = b_row + j * B_RPP;
+            long long m = r0 + row;
+            bool ok = row < BKP && m < r_end && b_col_ok;
+            if (ok) {
+                unsigned mu = (unsigned)m;                      // M < 2^31 (checked by the launcher)
+                int b = (int)(mu / (unsigned)HgWg);
+                int rem = (int)(mu - (unsigned)b * (unsigned)HgWg);
+                int y = (int)((unsigned)rem / (unsigned)p.Wg), x = rem - y * p.Wg;
+                int iy = y * p.IS + oy, ix = x * p.IS + ox;
+                ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                if (ok) {
+                    long long off = ((long long)(b * p.Hi + iy) * p.Wi + ix) * p.pix_stride + ci0 + b_cv * 8;
+                    b_reg[j] = ld_bf16x8(p.in + off);
+                }
+            }
+            if (!ok) b_reg[j] = zero_bf16x8();
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
+        unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            int row = a_row + j * A_RPP;
+            if (row < BKP) *reinterpret_cast<bf16x8*>(As + row * RSA + a_cv * 16) = a_reg[j];
+        }
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            int row = b_row + j * B_RPP;
+            if (row < BKP) *reinterpret_cast<bf16x8*>(Bs + row * RSB + b_cv * 16) = b_reg[j];
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read lane geometry: group g = lane>>4 ; inside the group lane 4q+pp supplies
+    // the address of pixel row q, channels 4pp..4pp+3.
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+    const int trow0 = 4 * g + q4;             // pixel row of read #0 inside a 32-pixel step
+    const int tcol = 4 * pp;                  // channel offset inside the 16-channel block
+
+    if (nk > 0) {
+        load_tiles(r_begin);
+        store_tiles(0);
+        __syncthreads();
+        int cur = 0;
+        for (int ks = 0; ks < nk; ++ks) {
+            const bool has_next = ks + 1 < nk;
+            if (has_next) load_tiles(r_begin + (long long)(ks + 1) * BKP);
+            const unsigned char* As = smem + cur * (A_BYTES + B_BYTES);
+            const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < BKP / 32; ++kk) {
+                bf16x8 af[MI], bfr[NI];
+                const int r0 = kk * 32 + trow0, r1 = r0 + 16;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    int col = wm * WTM + i * 16 + tcol;
+                    af[i] = tr_read_pair(As + r0 * RSA + col * 2, As + r1 * RSA + col * 2);
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    int col = wn * WTN + j * 16 + tcol;
+                    bfr[j] = tr_read_pair(Bs + r0 * RSB + col * 2, Bs + r1 * RSB + col * 2);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            if (has_next) store_tiles(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    if (nk == 0) return;
+    const int frow = lane & 15, fq = lane >> 4;
+    const long long wofs = (long long)p.widx[tap] * p.Ci;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            int c = ci0 + wn * WTN + j * 16 + frow;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int n = co0 + wm * WTM + i * 16 + fq * 4 + r;
+                if (n < p.N && c < p.Ci) atomicAdd(p.dw + (long long)n * p.wrow + wofs + c, acc[i][j][r]);
+            }
+        }
+}
+
+template <int BMO, int BNC, int WM, int WN>
+static int launch_wgrad(WgradParams& p, hipStream_t s, int target_blocks) {
+    int n_ct = (p.N + BMO - 1) / BMO;
+    int n_cin = (p.Ci + BNC - 1) / BNC;
+    long long tiles = (long long)n_ct * n_cin * p.T;
+    long long max_split = (p.M + 2 * BKP - 1) / (2 * BKP);     // at least two K steps per slice
+    long long split = (target_blocks + tiles - 1) / tiles;
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    long long rps = (p.M + split - 1) / split;
+    rps = (rps + BKP - 1) / BKP * BKP;
+    split = (p.M + rps - 1) / rps;
+    p.splitk = (int)split;
+    p.rows_per_split = rps;
+    long long nwg = tiles * split;
+    if (nwg > 0x7fffffffLL) return -2;
+    hipLaunchKernelGGL((wgrad_kernel<BMO, BNC, WM, WN>), dim3((unsigned)nwg), dim3(256), 0, s, p);
+    return pdt_launch_status();
+}
+
+// tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 64x32 (stem), 4 = 128x64
+PDT_API int pdt_conv_wgrad(const void* dy, const void* in, float* dw, long long M, int Hi, int Wi, int pix_stride,
+                           int Ci, int Hg, int Wg, int IS, int N, int ldy, int wrow, int T, const signed char* offy,
+                           const signed char* offx, const unsigned short* widx, int tile, int target_blocks,
+                           hipStream_t s) {
+    if (T <= 0 || T > MAX_TAPS) return -3;
+    if (M <= 0) return 0;
+    if (M >= 0x7fffffffLL) return -2;
+    if (ldy % 8 != 0 || Ci % 8 != 0 || pix_stride % 4 != 0) return -4;
+    WgradParams p;
+    p.dy = (const bf16*)dy; p.in = (const bf16*)in; p.dw = dw;
+    p.M = M; p.Hi = Hi; p.Wi = Wi; p.pix_stride = pix_stride; p.Ci = Ci;
+    p.Hg = Hg; p.Wg = Wg; p.IS = IS; p.N = N; p.ldy = ldy; p.wrow = wrow; p.T = T;
+    for (int i = 0; i < T; ++i) { p.offy[i] = offy[i]; p.offx[i] = offx[i]; p.widx[i] = widx[i]; }
+    for (int i = T; i < MAX_TAPS; ++i) { p.offy[i] = 0; p.offx[i] = 0; p.widx[i] = 0; }
+    if (target_blocks <= 0) target_blocks = 2048;
+    if (tile == 0) {
+        if (Ci <= 32) tile = 3;
+        else if (N <= 64 || Ci <= 64) tile = 2;
+        else tile = 1;
+    }
+    switch (tile) {
+        case 1: return launch_wgrad<128, 128, 2, 2>(p, s, target_blocks);
+        case 2: return launch_wgrad<64, 64, 2, 2>(p, s, target_blocks);
+        case 3: return launch_wgrad<64, 32, 2, 2>(p, s, target_blocks);
+        case 4: return launch_wgrad<128, 64, 2, 2>(p, s, target_blocks);
+        default: return -6;
+    }
+}

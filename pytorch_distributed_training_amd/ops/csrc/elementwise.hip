@@ -1,0 +1,437 @@
+// Memory-bound elementwise kernels for gfx950: fused SGD, BatchNorm apply / backward
+// elementwise, input layout transform, pooling, weight repacking.
+//
+// All of them stream NHWC bf16 data 16 bytes per lane (8 channels).  The grid is capped
+// (~8 blocks of 256 threads per CU) and grid-strided; since the grid stride in vectors is a
+// multiple of 256 and C/8 divides 256 for every channel count used by ResNets (C a power of
+// two between 64 and 2048), each thread always lands on the SAME 8 channels, so per-channel
+// constants are loaded into registers once.
+#include "common.h"
+
+static inline int ew_grid(long long nvec, int per_thread = 1) {
+    long long blocks = (nvec + 256LL * per_thread - 1) / (256LL * per_thread);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused SGD with momentum and weight decay over flat fp32 buffers (one pass):
+//   g' = g*grad_scale + wd*p ; m = first ? g' : mu*m + (1-damp)*g' ; p -= lr*(nesterov ? g'+mu*m : m)
+// also zeroes g (weight-gradient kernels accumulate into it) and rewrites the bf16 mirror.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                   float* __restrict__ m, bf16* __restrict__ pc, long long n4,
+                                                   float lr, float mu, float wd, float gscale, float damp,
+                                                   int nesterov, int first, int use_mom) {
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+        f32x4 gv = reinterpret_cast<f32x4*>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+        bf16x4 out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float grad = gv[k] * gscale + wd * pv[k];
+            float step = grad;
+            if (use_mom) {
+                float mm = first ? grad : mu * mv[k] + (1.0f - damp) * grad;
+                mv[k] = mm;
+                step = nesterov ? grad + mu * mm : mm;
+            }
+            pv[k] -= lr * step;
+            out[k] = f2bf(pv[k]);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        reinterpret_cast<f32x4*>(g)[i] = z;
+        if (pc) reinterpret_cast<bf16x4*>(pc)[i] = out;
+    }
+}
+
+PDT_API int pdt_sgd_step(float* p, float* g, float* m, void* pc, long long n, float lr, float mu, float wd,
+                         float gscale, float damp, int nesterov, int first, hipStream_t s) {
+    if (n % 4 != 0) return -1;
+    long long n4 = n / 4;
+    hipLaunchKernelGGL(sgd_kernel, dim3(ew_grid(n4, 2)), dim3(256), 0, s, p, g, m, (bf16*)pc, n4, lr, mu, wd,
+                       gscale, damp, nesterov, first, mu != 0.0f ? 1 : 0);
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm apply: out = relu?(y*scale[c] + shift[c] (+ residual))
+// ------------------------------------------------------------------------------------------
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ y, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift,
+                                                        const bf16* __restrict__ res, bf16* __restrict__ out,
+                                                        long long nvec, int cvec) {
+    long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvec) return;
+    int c0 = (int)(i % cvec) * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = scale[c0 + k]; sh[k] = shift[c0 + k]; }
+    for (; i < nvec; i += stride) {
+        bf16x8 v = ld_bf16x8(y + i * 8);
+        bf16x8 r;
+        if (RES) r = ld_bf16x8(res + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float f = bf2f(v[k]) * sc[k] + sh[k];
+            if (RES) f += bf2f(r[k]);
+            if (RELU) f = fmaxf(f, 0.0f);
+            o[k] = f2bf(f);
+        }
+        st_bf16x8(out + i * 8, o);
+    }
+}
+
+PDT_API int pdt_bn_apply(const void* y, const float* scale, const float* shift, const void* res, void* out,
+                         long long rows, int C, int relu, hipStream_t s) {
+    // the grid stride (grid*256 vectors) must be a multiple of C/8 so channels stay fixed per thread
+    if (C % 8 != 0 || C / 8 > 256 || 256 % (C / 8) != 0) return -1;
+    long long nvec = rows * (C / 8);
+    int cvec = C / 8;
+    dim3 grid(ew_grid(nvec, 4)), block(256);
+    const bf16* yy = (const bf16*)y; const bf16* rr = (const bf16*)res; bf16* oo = (bf16*)out;
+    if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, 0, s, yy, scale, shift, rr, oo, nvec, cvec);
+    else if (res) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, 0, s, yy, scale, shift, rr, oo, nvec, cvec);
+    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, block, 0, s, yy, scale, shift, rr, oo, nvec, cvec);
+    else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, 0, s, yy, scale, shift, rr, oo, nvec, cvec);
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm backward elementwise (fused ReLU mask):
+//   dy = g * mask ; dx = (dy - s0 - xhat*s1) * scale,  xhat = (y-mean)*invstd, [s0,s1] = sums*inv_count
+// folded to dx = dy*A + y*Bc + Cc with A = scale, Bc = -invstd*s1*scale, Cc = (mean*invstd*s1 - s0)*scale.
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_elemt_kernel(const bf16* __restrict__ g, const bf16* __restrict__ y,
+                                                            const bf16* __restrict__ msrc,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ sums, float inv_count,
+                                                            bf16* __restrict__ dx, long long nvec, int cvec, int C) {
+    long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvec) return;
+    int c0 = (int)(i % cvec) * 8;
+    float A[8], Bc[8], Cc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float s0 = sums[c0 + k] * inv_count, s1 = sums[C + c0 + k] * inv_count;
+        float sc = scale[c0 + k], is = invstd[c0 + k], mu = mean[c0 + k];
+        A[k] = sc;
+        Bc[k] = -is * s1 * sc;
+        Cc[k] = (mu * is * s1 - s0) * sc;
+        sh[k] = shift[c0 + k];
+    }
+    for (; i < nvec; i += stride) {
+        bf16x8 gv = ld_bf16x8(g + i * 8);
+        bf16x8 yv = ld_bf16x8(y + i * 8);
+        bf16x8 mv;
+        if (MODE == MASK_TENSOR) mv = ld_bf16x8(msrc + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float yy = bf2f(yv[k]);
+            float dy = bf2f(gv[k]);
+            if (MODE == MASK_TENSOR) dy = bf2f(mv[k]) > 0.0f ? dy : 0.0f;
+            if (MODE == MASK_RECOMPUTE) dy = (yy * A[k] + sh[k]) > 0.0f ? dy : 0.0f;
+            o[k] = f2bf(dy * A[k] + yy * Bc[k] + Cc[k]);
+        }
+        st_bf16x8(dx + i * 8, o);
+    }
+}
+
+PDT_API int pdt_bn_bwd_elemt(const void* g, const void* y, const void* msrc, const float* mean, const float* invstd,
+                             const float* scale, const float* shift, const float* sums, float inv_count, void* dx,
+                             long long rows, int C, int mode, hipStream_t s) {
+    if (C % 8 != 0 || C / 8 > 256 || 256 % (C / 8) != 0) return -1;
+    int cvec = C / 8;
+    long long nvec = rows * cvec;
+    dim3 grid(ew_grid(nvec, 4)), block(256);
+#define LAUNCH(M) hipLaunchKernelGGL((bn_bwd_elemt_kernel<M>), grid, block, 0, s, (const bf16*)g, (const bf16*)y, \
+                                     (const bf16*)msrc, mean, invstd, scale, shift, sums, inv_count, (bf16*)dx, nvec, cvec, C)
+    if (mode == MASK_NONE) LAUNCH(MASK_NONE);
+    else if (mode == MASK_TENSOR) LAUNCH(MASK_TENSOR);
+    else LAUNCH(MASK_RECOMPUTE);
+#undef LAUNCH
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// Input transform: loader batch -> zero-haloed NHWC4 bf16 stem input [B][H+6][Wp][4].
+// The stem 7x7/s2/p3 convolution then needs no bounds checks: pixel (h, w) of the image sits
+// at (h+3, w+3); channel 3 is zero.  Source is fp32 NCHW (already normalised) or uint8 NHWC
+// (normalised here with (x/255 - mean)/std).
+// ------------------------------------------------------------------------------------------
+template <bool U8>
+__global__ __launch_bounds__(256) void input_pad_kernel(const void* __restrict__ src, bf16* __restrict__ dst, int B,
+                                                         int H, int W, int Hp, int Wp, float m0, float m1, float m2,
+                                                         float i0, float i1, float i2) {
+    long long total = (long long)B * Hp * Wp;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        int wp = (int)(idx % Wp);
+        long long t = idx / Wp;
+        int hp = (int)(t % Hp);
+        int b = (int)(t / Hp);
+        int h = hp - 3, w = wp - 3;
+        bf16x4 o;
+        o[0] = o[1] = o[2] = o[3] = f2bf(0.0f);
+        if (h >= 0 && h < H && w >= 0 && w < W) {
+            if (U8) {
+                const unsigned char* p = (const unsigned char*)src + (((long long)b * H + h) * W + w) * 3;
+                o[0] = f2bf(((float)p[0] * (1.0f / 255.0f) - m0) * i0);
+                o[1] = f2bf(((float)p[1] * (1.0f / 255.0f) - m1) * i1);
+                o[2] = f2bf(((float)p[2] * (1.0f / 255.0f) - m2) * i2);
+            } else {
+                const float* p = (const float*)src + ((long long)b * 3 * H + h) * W + w;
+                long long plane = (long long)H * W;
+                o[0] = f2bf(p[0]);
+                o[1] = f2bf(p[plane]);
+                o[2] = f2bf(p[2 * plane]);
+            }
+        }
+        reinterpret_cast<bf16x4*>(dst)[idx] = o;
+    }
+}
+
+PDT_API int pdt_input_pad(const void* src, void* dst, int B, int H, int W, int Hp, int Wp, int is_u8, float m0,
+                          float m1, float m2, float s0, float s1, float s2, hipStream_t s) {
+    long long total = (long long)B * Hp * Wp;
+    dim3 grid(ew_grid(total, 2)), block(256);
+    if (is_u8) hipLaunchKernelGGL((input_pad_kernel<true>), grid, block, 0, s, src, (bf16*)dst, B, H, W, Hp, Wp, m0, m1, m2, 1.0f / s0, 1.0f / s1, 1.0f / s2);
+    else hipLaunchKernelGGL((input_pad_kernel<false>), grid, block, 0, s, src, (bf16*)dst, B, H, W, Hp, Wp, m0, m1, m2, 1.0f, 1.0f, 1.0f);
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// MaxPool 3x3 / stride 2 / pad 1, NHWC.  Forward stores the winning window position (0..8)
+// per output element; backward is a gather: every input element sums the gradients of the
+// (at most 2x2) windows that selected it, so no atomics are needed.  Ties: first maximum in
+// (r, s) scan order wins, like ATen.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ out,
+                                                           unsigned char* __restrict__ idx, int B, int H, int W,
+                                                           int C, int Ho, int Wo) {
+    int cvec = C / 8;
+    long long total = (long long)B * Ho * Wo * cvec;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int cv = (int)(i % cvec);
+        long long t = i / cvec;
+        int wo = (int)(t % Wo); t /= Wo;
+        int ho = (int)(t % Ho);
+        int b = (int)(t / Ho);
+        float best[8];
+        unsigned char bi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; bi[k] = 0; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            int h = ho * 2 - 1 + r;
+            if (h < 0 || h >= H) continue;
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) {
+                int w = wo * 2 - 1 + s2;
+                if (w < 0 || w >= W) continue;
+                bf16x8 v = ld_bf16x8(x + (((long long)b * H + h) * W + w) * C + cv * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float f = bf2f(v[k]);
+                    if (f > best[k]) { best[k] = f; bi[k] = (unsigned char)(r * 3 + s2); }
+                }
+            }
+        }
+        bf16x8 o;
+        unsigned long long packed = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { o[k] = f2bf(best[k]); packed |= (unsigned long long)bi[k] << (8 * k); }
+        st_bf16x8(out + i * 8, o);
+        reinterpret_cast<unsigned long long*>(idx)[i] = packed;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16* __restrict__ dout,
+                                                           const unsigned char* __restrict__ idx,
+                                                           bf16* __restrict__ dx, int B, int H, int W, int C, int Ho,
+                                                           int Wo) {
+    int cvec = C / 8;
+    long long total = (long long)B * H * W * cvec;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int cv = (int)(i % cvec);
+        long long t = i / cvec;
+        int w = (int)(t % W); t /= W;
+        int h = (int)(t % H);
+        int b = (int)(t / H);
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.0f;
+        // windows (ho, wo) covering (h, w): ho*2-1 <= h <= ho*2+1
+        int ho_lo = (h >= 1) ? (h - 1 + 1) / 2 : 0;   // ceil((h-1)/2)
+        int ho_hi = (h + 1) / 2;
+        int wo_lo = (w >= 1) ? (w - 1 + 1) / 2 : 0;
+        int wo_hi = (w + 1) / 2;
+        for (int ho = ho_lo; ho <= ho_hi && ho < Ho; ++ho) {
+            int r = h - (ho * 2 - 1);
+            for (int wo = wo_lo; wo <= wo_hi && wo < Wo; ++wo) {
+                int s2 = w - (wo * 2 - 1);
+                unsigned char want = (unsigned char)(r * 3 + s2);
+                long long o = (((long long)b * Ho + ho) * Wo + wo) * cvec + cv;
+                unsigned long long packed = reinterpret_cast<const unsigned long long*>(idx)[o];
+                bf16x8 gv = ld_bf16x8(dout + o * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if ((unsigned char)(packed >> (8 * k)) == want) acc[k] += bf2f(gv[k]);
+            }
+        }
+        bf16x8 o8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o8[k] = f2bf(acc[k]);
+        st_bf16x8(dx + i * 8, o8);
+    }
+}
+
+PDT_API int pdt_maxpool_fwd(const void* x, void* out, void* idx, int B, int H, int W, int C, int Ho, int Wo,
+                            hipStream_t s) {
+    if (C % 8) return -1;
+    long long total = (long long)B * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total, 1)), dim3(256), 0, s, (const bf16*)x, (bf16*)out,
+                       (unsigned char*)idx, B, H, W, C, Ho, Wo);
+    return pdt_launch_status();
+}
+
+PDT_API int pdt_maxpool_bwd(const void* dout, const void* idx, void* dx, int B, int H, int W, int C, int Ho, int Wo,
+                            hipStream_t s) {
+    if (C % 8) return -1;
+    long long total = (long long)B * H * W * (C / 8);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total, 1)), dim3(256), 0, s, (const bf16*)dout,
+                       (const unsigned char*)idx, (bf16*)dx, B, H, W, C, Ho, Wo);
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// Global average pool [B, HW, C] -> [B, C] and its backward (broadcast / HW).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, int B,
+                                                           int HW, int C) {
+    int cvec = C / 8;
+    long long total = (long long)B * cvec;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int cv = (int)(i % cvec);
+    int b = (int)(i / cvec);
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.0f;
+    const bf16* p = x + (long long)b * HW * C + cv * 8;
+    for (int j = 0; j < HW; ++j) {
+        bf16x8 v = ld_bf16x8(p + (long long)j * C);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += bf2f(v[k]);
+    }
+    float inv = 1.0f / (float)HW;
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = f2bf(acc[k] * inv);
+    st_bf16x8(out + i * 8, o);
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf16* __restrict__ dp, bf16* __restrict__ dx, int B,
+                                                           int HW, int C) {
+    int cvec = C / 8;
+    long long total = (long long)B * HW * cvec;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    float inv = 1.0f / (float)HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int cv = (int)(i % cvec);
+        int b = (int)(i / ((long long)HW * cvec));
+        bf16x8 v = ld_bf16x8(dp + ((long long)b * cvec + cv) * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = f2bf(bf2f(v[k]) * inv);
+        st_bf16x8(dx + i * 8, o);
+    }
+}
+
+PDT_API int pdt_avgpool_fwd(const void* x, void* out, int B, int HW, int C, hipStream_t s) {
+    if (C % 8) return -1;
+    long long total = (long long)B * (C / 8);
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, (const bf16*)x, (bf16*)out, B, HW, C);
+    return pdt_launch_status();
+}
+
+PDT_API int pdt_avgpool_bwd(const void* dp, void* dx, int B, int HW, int C, hipStream_t s) {
+    if (C % 8) return -1;
+    long long total = (long long)B * HW * (C / 8);
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_grid(total, 1)), dim3(256), 0, s, (const bf16*)dp, (bf16*)dx, B, HW, C);
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight repacking (tiny, once per optimizer step).
+//   transpose:  w[Co][T][Ci] -> wt[Ci][T][Co_pad]  (data-gradient operand; Co_pad >= Co, pad = 0)
+//   stem pack:  w[64][7][7][3] -> wp[64][7][32]     (k = s*4 + c, zero where c == 3 or s == 7)
+//   stem unpack-add: dwp[64][7][32] fp32 -> dw[64][7][7][3] += ...
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_w_kernel(const bf16* __restrict__ w, bf16* __restrict__ wt, int Co,
+                                                           int T, int Ci, int Co_pad) {
+    long long total = (long long)Ci * T * Co_pad;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int co = (int)(i % Co_pad);
+        long long t2 = i / Co_pad;
+        int t = (int)(t2 % T);
+        int ci = (int)(t2 / T);
+        wt[i] = (co < Co) ? w[((long long)co * T + t) * Ci + ci] : f2bf(0.0f);
+    }
+}
+
+PDT_API int pdt_transpose_w(const void* w, void* wt, int Co, int T, int Ci, int Co_pad, hipStream_t s) {
+    long long total = (long long)Ci * T * Co_pad;
+    hipLaunchKernelGGL(transpose_w_kernel, dim3(ew_grid(total, 1)), dim3(256), 0, s, (const bf16*)w, (bf16*)wt, Co, T, Ci, Co_pad);
+    return pdt_launch_status();
+}
+
+__global__ __launch_bounds__(256) void stem_pack_kernel(const bf16* __restrict__ w, bf16* __restrict__ wp, int Co) {
+    int total = Co * 7 * 32;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int k = i % 32;
+    int r = (i / 32) % 7;
+    int co = i / (32 * 7);
+    int s2 = k / 4, c = k % 4;
+    wp[i] = (s2 < 7 && c < 3) ? w[((co * 7 + r) * 7 + s2) * 3 + c] : f2bf(0.0f);
+}
+
+__global__ __launch_bounds__(256) void stem_unpack_add_kernel(const float* __restrict__ dwp, float* __restrict__ dw,
+                                                               int Co) {
+    int total = Co * 7 * 7 * 3;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int c = i % 3;
+    int s2 = (i / 3) % 7;
+    int r = (i / 21) % 7;
+    int co = i / 147;
+    dw[i] += dwp[(co * 7 + r) * 32 + s2 * 4 + c];
+}
+
+PDT_API int pdt_stem_pack(const void* w, void* wp, int Co, hipStream_t s) {
+    hipLaunchKernelGGL(stem_pack_kernel, dim3(cdiv(Co * 7 * 32, 256)), dim3(256), 0, s, (const bf16*)w, (bf16*)wp, Co);
+    return pdt_launch_status();
+}
+
+PDT_API int pdt_stem_unpack_add(const float* dwp, float* dw, int Co, hipStream_t s) {
+    hipLaunchKernelGGL(stem_unpack_add_kernel, dim3(cdiv(Co * 147, 256)), dim3(256), 0, s, dwp, dw, Co);
+    return pdt_launch_status();
+}

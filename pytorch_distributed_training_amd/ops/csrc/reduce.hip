@@ -1,0 +1,388 @@
+// Reduction kernels for gfx950: BatchNorm statistics, BatchNorm backward reduce, BN finalize,
+// fused softmax cross-entropy (+ validation metrics) and bias-gradient column sums.
+//
+// Per-channel reductions over an NHWC tensor are column sums of a [rows][C] matrix.  A block
+// owns a slab of at most 256 channels (32 lanes x 8 channels, 16 B per lane) and a chunk of
+// rows; its 2 x slab partial sums are added with float atomics into one of NREP replica rows
+// of a small persistent accumulator [NREP][2][C] (replicas spread the contention that a single
+// row of addresses would see from ~1000 workgroups).  A tiny second kernel folds the replicas,
+// ZEROES them for the next use and produces the per-channel result, so no memset launch is
+// needed.  The same accumulator format is fed by the convolution epilogue (conv_igemm.hip).
+//
+// Statistics are accumulated SHIFTED by a per-channel value s (the BatchNorm running mean):
+// sum(y - s) and sum((y - s)^2).  var = E[(y-s)^2] - E[y-s]^2 then only cancels when the batch
+// mean is many standard deviations away from the running mean, and -- because SyncBatchNorm
+// keeps running means identical on all ranks -- the shifted moments of different ranks can be
+// averaged by ONE all-reduce.
+#include "common.h"
+
+#define NREP 16
+
+// ------------------------------------------------------------------------------------------
+// Column reduce skeleton
+// ------------------------------------------------------------------------------------------
+struct ColGeom {
+    int cv;        // column vectors (8 channels each) per block: min(C/8, 32)
+    int rl;        // row lanes per block = 256 / cv
+    int slabs;     // column slabs = (C/8) / cv
+    int rows_per_block;
+    int row_chunks;
+};
+
+static inline ColGeom col_geom(long long rows, int C) {
+    ColGeom g;
+    int cvec = C / 8;
+    g.cv = cvec < 32 ? cvec : 32;
+    g.rl = 256 / g.cv;
+    g.slabs = cvec / g.cv;
+    long long target_blocks = 2048 / g.slabs;
+    long long rpb = (rows + target_blocks - 1) / target_blocks;
+    long long min_rpb = (long long)g.rl * 8;
+    if (rpb < min_rpb) rpb = min_rpb;
+    rpb = (rpb + g.rl - 1) / g.rl * g.rl;
+    g.rows_per_block = (int)rpb;
+    g.row_chunks = (int)((rows + rpb - 1) / rpb);
+    return g;
+}
+
+// Reduce the per-thread 2x8 partials over the row lanes of the block and add them to the
+// replica accumulator.  acc0/acc1: per-thread partial sums for its 8 channels.
+__device__ __forceinline__ void block_col_reduce_atomic(float (&a0)[8], float (&a1)[8], int cv, int rl, int col_lane,
+                                                        int row_lane, int c_base, int C, float* __restrict__ acc) {
+    __shared__ float red[2][256][8 + 1];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { red[0][threadIdx.x][k] = a0[k]; red[1][threadIdx.x][k] = a1[k]; }
+    __syncthreads();
+    // thread t < cv*8*2 finalises one (which, column) pair
+    int ncol = cv * 8;
+    for (int t = threadIdx.x; t < 2 * ncol; t += 256) {
+        int which = t / ncol;
+        int col = t % ncol;
+        int cl = col / 8, k = col % 8;
+        float s = 0.0f;
+        for (int r = 0; r < rl; ++r) s += red[which][r * cv + cl][k];
+        float* dst = acc + ((size_t)(blockIdx.x % NREP) * 2 + which) * C + c_base + col;
+        atomicAdd(dst, s);
+    }
+}
+
+// ---- BN statistics: acc += [sum(y - s), sum((y - s)^2)] -----------------------------------
+__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16* __restrict__ y, const float* __restrict__ shift,
+                                                        float* __restrict__ acc, long long rows, int C, int cv,
+                                                        int rl, int slabs, int rows_per_block) {
+    int slab = blockIdx.x % slabs;
+    int chunk = blockIdx.x / slabs;
+    int col_lane = threadIdx.x % cv;
+    int row_lane = threadIdx.x / cv;
+    int c_base = slab * cv * 8;
+    int c0 = c_base + col_lane * 8;
+    float s[8], a0[8], a1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s[k] = shift ? shift[c0 + k] : 0.0f; a0[k] = 0.0f; a1[k] = 0.0f; }
+    long long r0 = (long long)chunk * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (long long r = r0 + row_lane; r < r1; r += rl) {
+        bf16x8 v = ld_bf16x8(y + r * C + c0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float d = bf2f(v[k]) - s[k];
+            a0[k] += d;
+            a1[k] += d * d;
+        }
+    }
+    block_col_reduce_atomic(a0, a1, cv, rl, col_lane, row_lane, c_base, C, acc);
+}
+
+PDT_API int pdt_bn_stats_accum(const void* y, const float* shift, float* acc, long long rows, int C, hipStream_t s) {
+    if (C % 8 != 0 || (C / 8 < 32 ? 256 % (C / 8) != 0 : (C / 8) % 32 != 0)) return -1;
+    ColGeom g = col_geom(rows, C);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(g.slabs * g.row_chunks), dim3(256), 0, s, (const bf16*)y, shift, acc, rows,
+                       C, g.cv, g.rl, g.slabs, g.rows_per_block);
+    return pdt_launch_status();
+}
+
+// ---- replicas -> shifted moments [E[y-s], E[(y-s)^2]] ; zero the replicas -------------------
+__global__ __launch_bounds__(256) void bn_moments_kernel(float* __restrict__ acc, float* __restrict__ moments, int C,
+                                                          float inv_count) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 2*C
+    if (i >= 2 * C) return;
+    float s = 0.0f;
+#pragma unroll
+    for (int r = 0; r < NREP; ++r) {
+        s += acc[(size_t)r * 2 * C + i];
+        acc[(size_t)r * 2 * C + i] = 0.0f;
+    }
+    moments[i] = s * inv_count;
+}
+
+PDT_API int pdt_bn_moments(float* acc, float* moments, int C, float inv_count, hipStream_t s) {
+    hipLaunchKernelGGL(bn_moments_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, acc, moments, C, inv_count);
+    return pdt_launch_status();
+}
+
+// ---- finalize: (summed shifted moments) -> scale, shift, mean, invstd ; update running stats --
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ moments, float inv_world,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ rmean,
+                                                           float* __restrict__ rvar, float momentum, float eps,
+                                                           float unbias, float* __restrict__ scale,
+                                                           float* __restrict__ shift, float* __restrict__ mean_out,
+                                                           float* __restrict__ invstd_out, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = rmean[c];
+    float m0 = moments[c] * inv_world;
+    float m1 = moments[C + c] * inv_world;
+    float mean = s + m0;
+    float var = fmaxf(m1 - m0 * m0, 0.0f);
+    float invstd = rsqrtf(var + eps);
+    float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    mean_out[c] = mean;
+    invstd_out[c] = invstd;
+    rmean[c] = (1.0f - momentum) * s + momentum * mean;
+    rvar[c] = (1.0f - momentum) * rvar[c] + momentum * var * unbias;
+}
+
+PDT_API int pdt_bn_finalize(const float* moments, float inv_world, const float* gamma, const float* beta,
+                            float* rmean, float* rvar, float momentum, float eps, float unbias, float* scale,
+                            float* shift, float* mean_out, float* invstd_out, int C, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, moments, inv_world, gamma, beta, rmean,
+                       rvar, momentum, eps, unbias, scale, shift, mean_out, invstd_out, C);
+    return pdt_launch_status();
+}
+
+__global__ __launch_bounds__(256) void bn_eval_affine_kernel(const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              const float* __restrict__ rmean,
+                                                              const float* __restrict__ rvar, float eps,
+                                                              float* __restrict__ scale, float* __restrict__ shift,
+                                                              int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sc = gamma[c] * rsqrtf(rvar[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rmean[c] * sc;
+}
+
+PDT_API int pdt_bn_eval_affine(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
+                               float* scale, float* shift, int C, hipStream_t s) {
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, gamma, beta, rmean, rvar, eps, scale,
+                       shift, C);
+    return pdt_launch_status();
+}
+
+// ---- BN backward reduce: acc += [sum(dy), sum(dy * (y - mean))], dy = g * relu-mask ---------
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restrict__ g, const bf16* __restrict__ y,
+                                                             const bf16* __restrict__ msrc,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, float* __restrict__ acc,
+                                                             long long rows, int C, int cv, int rl, int slabs,
+                                                             int rows_per_block) {
+    int slab = blockIdx.x % slabs;
+    int chunk = blockIdx.x / slabs;
+    int col_lane = threadIdx.x % cv;
+    int row_lane = threadIdx.x / cv;
+    int c_base = slab * cv * 8;
+    int c0 = c_base + col_lane * 8;
+    float mu[8], sc[8], sh[8], a0[8], a1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mu[k] = mean[c0 + k];
+        sc[k] = scale[c0 + k];
+        sh[k] = shift[c0 + k];
+        a0[k] = 0.0f;
+        a1[k] = 0.0f;
+    }
+    long long r0 = (long long)chunk * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (long long r = r0 + row_lane; r < r1; r += rl) {
+        bf16x8 gv = ld_bf16x8(g + r * C + c0);
+        bf16x8 yv = ld_bf16x8(y + r * C + c0);
+        bf16x8 mv;
+        if (MODE == MASK_TENSOR) mv = ld_bf16x8(msrc + r * C + c0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float yy = bf2f(yv[k]);
+            float dy = bf2f(gv[k]);
+            if (MODE == MASK_TENSOR) dy = bf2f(mv[k]) > 0.0f ? dy : 0.0f;
+            if (MODE == MASK_RECOMPUTE) dy = (yy * sc[k] + sh[k]) > 0.0f ? dy : 0.0f;
+            a0[k] += dy;
+            a1[k] += dy * (yy - mu[k]);
+        }
+    }
+    block_col_reduce_atomic(a0, a1, cv, rl, col_lane, row_lane, c_base, C, acc);
+}
+
+PDT_API int pdt_bn_bwd_reduce_accum(const void* g, const void* y, const void* msrc, const float* mean,
+                                    const float* scale, const float* shift, float* acc, long long rows, int C,
+                                    int mode, hipStream_t s) {
+    if (C % 8 != 0 || (C / 8 < 32 ? 256 % (C / 8) != 0 : (C / 8) % 32 != 0)) return -1;
+    ColGeom gm = col_geom(rows, C);
+    dim3 grid(gm.slabs * gm.row_chunks), block(256);
+#define LAUNCH(M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M>), grid, block, 0, s, (const bf16*)g, (const bf16*)y, \
+                                     (const bf16*)msrc, mean, scale, shift, acc, rows, C, gm.cv, gm.rl, gm.slabs, gm.rows_per_block)
+    if (mode == MASK_NONE) LAUNCH(MASK_NONE);
+    else if (mode == MASK_TENSOR) LAUNCH(MASK_TENSOR);
+    else LAUNCH(MASK_RECOMPUTE);
+#undef LAUNCH
+    return pdt_launch_status();
+}
+
+// replicas -> sums [sum(dy), sum(dy*xhat)] ; dbeta += sums[0], dgamma += sums[1] ; zero replicas
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(float* __restrict__ acc, const float* __restrict__ invstd,
+                                                           float* __restrict__ sums, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < NREP; ++r) {
+        size_t base = (size_t)r * 2 * C;
+        s0 += acc[base + c];
+        s1 += acc[base + C + c];
+        acc[base + c] = 0.0f;
+        acc[base + C + c] = 0.0f;
+    }
+    s1 *= invstd[c];
+    sums[c] = s0;
+    sums[C + c] = s1;
+    if (dbeta) dbeta[c] += s0;
+    if (dgamma) dgamma[c] += s1;
+}
+
+PDT_API int pdt_bn_bwd_sums(float* acc, const float* invstd, float* sums, float* dgamma, float* dbeta, int C,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, acc, invstd, sums, dgamma, dbeta, C);
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// Softmax cross-entropy, one wave per row, fp32 math, single pass over the logits held in
+// registers (N <= 64*REG columns).  Writes dlogits = (softmax - onehot) * gscale / B into a
+// row of stride ld_out (columns >= N zeroed up to ld_out: the padded reduction dimension of
+// the classifier's data-gradient GEMM) and adds loss_i / B into *loss.
+// ------------------------------------------------------------------------------------------
+#define CE_REG 32   // up to 2048 classes
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const bf16* __restrict__ logits,
+                                                          const long long* __restrict__ labels,
+                                                          bf16* __restrict__ dlogits, float* __restrict__ loss, int B,
+                                                          int N, int ld_in, int ld_out, float gscale) {
+    int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    int row = blockIdx.x * 4 + wave;
+    if (row >= B) return;
+    const bf16* src = logits + (size_t)row * ld_in;
+    float v[CE_REG];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < CE_REG; ++j) {
+        int c = lane + j * 64;
+        v[j] = (c < N) ? bf2f(src[c]) : -INFINITY;
+        mx = fmaxf(mx, v[j]);
+    }
+    mx = wave_max(mx);
+    float se = 0.0f;
+#pragma unroll
+    for (int j = 0; j < CE_REG; ++j) {
+        int c = lane + j * 64;
+        float e = (c < N) ? __expf(v[j] - mx) : 0.0f;
+        v[j] = e;
+        se += e;
+    }
+    se = wave_sum(se);
+    int lab = (int)labels[row];
+    float inv = 1.0f / se;
+    float gs = gscale / (float)B;
+    bf16* dst = dlogits + (size_t)row * ld_out;
+#pragma unroll
+    for (int j = 0; j < CE_REG; ++j) {
+        int c = lane + j * 64;
+        if (c < ld_out) {
+            float p = (c < N) ? v[j] * inv : 0.0f;
+            float d = (c < N) ? (p - (c == lab ? 1.0f : 0.0f)) * gs : 0.0f;
+            dst[c] = f2bf(d);
+        }
+    }
+    if (lane == 0) {
+        float lab_logit = (lab >= 0 && lab < N) ? bf2f(src[lab]) : mx;
+        float li = logf(se) + mx - lab_logit;
+        atomicAdd(loss, li / (float)B);
+    }
+}
+
+PDT_API int pdt_softmax_ce(const void* logits, const void* labels, void* dlogits, float* loss, int B, int N,
+                           int ld_in, int ld_out, float gscale, hipStream_t s) {
+    if (N > 64 * CE_REG || ld_out > 64 * CE_REG) return -1;
+    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, (const bf16*)logits,
+                       (const long long*)labels, (bf16*)dlogits, loss, B, N, ld_in, ld_out, gscale);
+    return pdt_launch_status();
+}
+
+// Validation metrics: out[4] += [sum of per-row loss, #(rank<1), #(rank<5), rows]
+__global__ __launch_bounds__(256) void ce_metrics_kernel(const bf16* __restrict__ logits,
+                                                          const long long* __restrict__ labels,
+                                                          float* __restrict__ out, int B, int N, int ld_in) {
+    int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    int row = blockIdx.x * 4 + wave;
+    if (row >= B) return;
+    const bf16* src = logits + (size_t)row * ld_in;
+    int lab = (int)labels[row];
+    float lab_logit = (lab >= 0 && lab < N) ? bf2f(src[lab]) : INFINITY;
+    float mx = -INFINITY;
+    float v[CE_REG];
+    int greater = 0;
+#pragma unroll
+    for (int j = 0; j < CE_REG; ++j) {
+        int c = lane + j * 64;
+        v[j] = (c < N) ? bf2f(src[c]) : -INFINITY;
+        mx = fmaxf(mx, v[j]);
+        greater += (c < N && v[j] > lab_logit) ? 1 : 0;
+    }
+    mx = wave_max(mx);
+    float se = 0.0f;
+#pragma unroll
+    for (int j = 0; j < CE_REG; ++j) {
+        int c = lane + j * 64;
+        se += (c < N) ? __expf(v[j] - mx) : 0.0f;
+    }
+    se = wave_sum(se);
+    float gsum = wave_sum((float)greater);
+    if (lane == 0) {
+        atomicAdd(out + 0, logf(se) + mx - lab_logit);
+        atomicAdd(out + 1, gsum < 1.0f ? 1.0f : 0.0f);
+        atomicAdd(out + 2, gsum < 5.0f ? 1.0f : 0.0f);
+        atomicAdd(out + 3, 1.0f);
+    }
+}
+
+PDT_API int pdt_ce_metrics(const void* logits, const void* labels, float* out, int B, int N, int ld_in,
+                           hipStream_t s) {
+    if (N > 64 * CE_REG) return -1;
+    hipError_t e = hipMemsetAsync(out, 0, 4 * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(ce_metrics_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, (const bf16*)logits,
+                       (const long long*)labels, out, B, N, ld_in);
+    return pdt_launch_status();
+}
+
+// Column sums of a small [rows][ld] bf16 matrix: out[c] += sum_r x[r][c]  (classifier bias gradient)
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, float* __restrict__ out, int rows,
+                                                      int N, int ld) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.0f;
+    for (int r = 0; r < rows; ++r) s += bf2f(x[(size_t)r * ld + c]);
+    out[c] += s;
+}
+
+PDT_API int pdt_colsum_add(const void* x, float* out, int rows, int N, int ld, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, (const bf16*)x, out, rows, N, ld);
+    return pdt_launch_status();
+}

@@ -1,0 +1,501 @@
+"""HIP op backend: ctypes bindings to the gfx950 kernel library.
+
+Same function contract as :mod:`.ref` (which documents the math); tensors are NHWC bf16
+on a GPU, per-channel vectors fp32.  Kernels are enqueued on the CURRENT torch stream.
+The library must have been built (``python -m pytorch_distributed_training_amd.ops.build``);
+importing this module without it raises -- there is no silent fall-back.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import build as _build
+from .ref import MASK_NONE, MASK_RECOMPUTE, MASK_TENSOR  # noqa: F401  (re-exported)
+
+name = "hip"
+needs_wt = True
+NREP = 16
+
+_LIB_PATH = _build.LIB
+if not os.path.exists(_LIB_PATH):
+    raise ImportError(
+        f"{_LIB_PATH} is missing: build the gfx950 kernels first with "
+        "`python -m pytorch_distributed_training_amd.ops.build`"
+    )
+_lib = ctypes.CDLL(_LIB_PATH)
+
+_vp, _i, _ll, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
+
+
+def _sig(fn_name: str, *argtypes) -> None:
+    fn = getattr(_lib, fn_name)
+    fn.argtypes = list(argtypes)
+    fn.restype = ctypes.c_int
+
+
+_sig("pdt_sgd_step", _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _i, _vp)
+_sig("pdt_bn_apply", _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp)
+_sig("pdt_bn_bwd_elemt", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _ll, _i, _i, _vp)
+_sig("pdt_input_pad", _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _vp)
+_sig("pdt_maxpool_fwd", _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
+_sig("pdt_maxpool_bwd", _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
+_sig("pdt_avgpool_fwd", _vp, _vp, _i, _i, _i, _vp)
+_sig("pdt_avgpool_bwd", _vp, _vp, _i, _i, _i, _vp)
+_sig("pdt_transpose_w", _vp, _vp, _i, _i, _i, _i, _vp)
+_sig("pdt_stem_pack", _vp, _vp, _i, _vp)
+_sig("pdt_stem_unpack_add", _vp, _vp, _i, _vp)
+_sig("pdt_bn_stats_accum", _vp, _vp, _vp, _ll, _i, _vp)
+_sig("pdt_bn_moments", _vp, _vp, _i, _f, _vp)
+_sig("pdt_bn_finalize", _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _vp)
+_sig("pdt_bn_eval_affine", _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp)
+_sig("pdt_bn_bwd_reduce_accum", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp)
+_sig("pdt_bn_bwd_sums", _vp, _vp, _vp, _vp, _vp, _i, _vp)
+_sig("pdt_softmax_ce", _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp)
+_sig("pdt_ce_metrics", _vp, _vp, _vp, _i, _i, _i, _vp)
+_sig("pdt_colsum_add", _vp, _vp, _i, _i, _i, _vp)
+_sig("pdt_conv_igemm", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+     _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp)
+_sig("pdt_conv_wgrad", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp)
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise HipKernelError(f"{what} failed with status {rc}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _bf16c(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.dtype != torch.bfloat16 or not t.is_cuda:
+        raise TypeError(f"{what}: expected a bf16 GPU tensor, got {t.dtype} on {t.device}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _f32c(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise TypeError(f"{what}: expected an fp32 GPU tensor, got {t.dtype} on {t.device}")
+    if not t.is_contiguous():
+        raise ValueError(f"{what}: must be contiguous")
+    return t
+
+
+# --------------------------------------------------------------------------- small caches
+_acc_cache: Dict[Tuple[int, int, str], torch.Tensor] = {}
+
+
+def _accumulator(device: torch.device, C: int, kind: str) -> torch.Tensor:
+    """Persistent zero-initialised ``[NREP, 2, C]`` accumulator (kernels re-zero it after use)."""
+    key = (device.index or 0, C, kind)
+    acc = _acc_cache.get(key)
+    if acc is None:
+        acc = torch.zeros(NREP * 2 * C, dtype=torch.float32, device=device)
+        _acc_cache[key] = acc
+    return acc
+
+
+class _Taps:
+    __slots__ = ("T", "offy", "offx", "widx", "_keep")
+
+    def __init__(self, offy, offx, widx) -> None:
+        self.T = len(offy)
+        oy = np.ascontiguousarray(np.asarray(offy, dtype=np.int8))
+        ox = np.ascontiguousarray(np.asarray(offx, dtype=np.int8))
+        wi = np.ascontiguousarray(np.asarray(widx, dtype=np.uint16))
+        self._keep = (oy, ox, wi)
+        self.offy = oy.ctypes.data if self.T else None
+        self.offx = ox.ctypes.data if self.T else None
+        self.widx = wi.ctypes.data if self.T else None
+
+
+_tap_cache: Dict[tuple, object] = {}
+
+
+def _fprop_taps(R: int, S: int, pad: int) -> _Taps:
+    key = ("f", R, S, pad)
+    if key not in _tap_cache:
+        oy, ox, wi = [], [], []
+        for r in range(R):
+            for s in range(S):
+                oy.append(r - pad); ox.append(s - pad); wi.append(r * S + s)
+        _tap_cache[key] = _Taps(oy, ox, wi)
+    return _tap_cache[key]
+
+
+def _dgrad_taps(R: int, S: int, pad: int, stride: int, ph: int, pw: int) -> _Taps:
+    key = ("d", R, S, pad, stride, ph, pw)
+    if key not in _tap_cache:
+        oy, ox, wi = [], [], []
+        for r in range(R):
+            if (ph + pad - r) % stride:
+                continue
+            for s in range(S):
+                if (pw + pad - s) % stride:
+                    continue
+                oy.append((ph + pad - r) // stride); ox.append((pw + pad - s) // stride); wi.append(r * S + s)
+        _tap_cache[key] = _Taps(oy, ox, wi)
+    return _tap_cache[key]
+
+
+def _stem_taps() -> _Taps:
+    key = ("stem",)
+    if key not in _tap_cache:
+        _tap_cache[key] = _Taps(list(range(7)), [0] * 7, list(range(7)))
+    return _tap_cache[key]
+
+
+def _igemm(inp, wgt, out, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, ldo, wrow, taps: _Taps,
+           addend=None, mask=None, bias=None, stat_acc=None, stat_shift=None, tile: int = 0) -> None:
+    rc = _lib.pdt_conv_igemm(_p(inp), _p(wgt), _p(out), _p(addend), _p(mask), _p(bias), _p(stat_acc), _p(stat_shift),
+                             M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, ldo, wrow, taps.T,
+                             taps.offy, taps.offx, taps.widx, tile, _stream())
+    _check(rc, "pdt_conv_igemm")
+
+
+def _wgrad(dy, inp, dw, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow, taps: _Taps, tile: int = 0,
+           target_blocks: int = 0) -> None:
+    rc = _lib.pdt_conv_wgrad(_p(dy), _p(inp), _p(dw), M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow, taps.T,
+                             taps.offy, taps.offx, taps.widx, tile, target_blocks, _stream())
+    _check(rc, "pdt_conv_wgrad")
+
+
+def _moments_from_acc(acc: torch.Tensor, C: int, count: int) -> torch.Tensor:
+    moments = torch.empty(2, C, dtype=torch.float32, device=acc.device)
+    _check(_lib.pdt_bn_moments(_p(acc), _p(moments), C, 1.0 / float(count), _stream()), "pdt_bn_moments")
+    return moments
+
+
+# --------------------------------------------------------------------------- input / stem
+def input_transform(img: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Loader batch (fp32 NCHW normalised, or uint8 NHWC raw) -> zero-haloed NHWC4 bf16 image
+    ``[B, H+6, Wp, 4]`` with the picture at offset (3, 3)."""
+    if not img.is_cuda:
+        raise TypeError("input_transform: the batch must already be on the GPU")
+    img = img.contiguous()
+    if img.dtype == torch.uint8:
+        B, H, W, C = img.shape
+        is_u8 = 1
+    elif img.dtype == torch.float32:
+        B, C, H, W = img.shape
+        is_u8 = 0
+    else:
+        raise TypeError(f"input_transform: unsupported image dtype {img.dtype}")
+    if C != 3:
+        raise ValueError("input_transform: expected 3 colour channels")
+    Hp, Wp = H + 6, (W + 8 + 1) // 2 * 2
+    out = torch.empty(B, Hp, Wp, 4, dtype=torch.bfloat16, device=img.device)
+    m, s = _host_mean_std(mean, std)
+    rc = _lib.pdt_input_pad(_p(img), _p(out), B, H, W, Hp, Wp, is_u8, m[0], m[1], m[2], s[0], s[1], s[2], _stream())
+    _check(rc, "pdt_input_pad")
+    out._pdt_hw = (H, W)
+    return out
+
+
+_ms_cache: Dict[int, tuple] = {}
+
+
+def _host_mean_std(mean: torch.Tensor, std: torch.Tensor):
+    key = mean.data_ptr()
+    if key not in _ms_cache:
+        _ms_cache[key] = (tuple(float(v) for v in mean.tolist()), tuple(float(v) for v in std.tolist()))
+    return _ms_cache[key]
+
+
+def prepare_stem_weight(w: torch.Tensor) -> torch.Tensor:
+    """``[Co, 7, 7, 3]`` -> packed ``[Co, 7, 32]`` (k = s*4 + c, zero padded)."""
+    w = _bf16c(w, "prepare_stem_weight")
+    Co = w.shape[0]
+    wp = torch.empty(Co, 7, 32, dtype=torch.bfloat16, device=w.device)
+    _check(_lib.pdt_stem_pack(_p(w), _p(wp), Co, _stream()), "pdt_stem_pack")
+    return wp
+
+
+def _stem_geometry(x0: torch.Tensor):
+    B, Hp, Wp, _ = x0.shape
+    H, W = getattr(x0, "_pdt_hw", (Hp - 6, Wp - 8))
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    return B, Hp, Wp, Ho, Wo
+
+
+def stem_fprop(x0: torch.Tensor, wp: torch.Tensor, stat_shift: Optional[torch.Tensor]):
+    B, Hp, Wp, Ho, Wo = _stem_geometry(x0)
+    Co = wp.shape[0]
+    y = torch.empty(B, Ho, Wo, Co, dtype=torch.bfloat16, device=x0.device)
+    M = B * Ho * Wo
+    acc = _accumulator(x0.device, Co, "stats") if stat_shift is not None else None
+    _igemm(x0, wp, y, M, Hp, Wp, 4, 32, Ho, Wo, 2, Ho, Wo, 1, 0, 0, Co, Co, 7 * 32, _stem_taps(),
+           stat_acc=acc, stat_shift=stat_shift)
+    moments = _moments_from_acc(acc, Co, M) if acc is not None else None
+    return y, moments
+
+
+def stem_wgrad(x0: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) -> None:
+    B, Hp, Wp, Ho, Wo = _stem_geometry(x0)
+    dy = _bf16c(dy, "stem_wgrad dy")
+    Co = dy.shape[-1]
+    scratch = torch.zeros(Co, 7, 32, dtype=torch.float32, device=dy.device)
+    _wgrad(dy, x0, scratch, B * Ho * Wo, Hp, Wp, 4, 32, Ho, Wo, 2, Co, Co, 7 * 32, _stem_taps())
+    _check(_lib.pdt_stem_unpack_add(_p(scratch), _p(dw), Co, _stream()), "pdt_stem_unpack_add")
+
+
+# --------------------------------------------------------------------------- convolution
+def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pad: int,
+               stat_shift: Optional[torch.Tensor] = None, tile: int = 0):
+    x = _bf16c(x, "conv_fprop x")
+    w = _bf16c(w, "conv_fprop w")
+    B, Hi, Wi, Ci = x.shape
+    Co = w.shape[0]
+    Ho, Wo = (Hi + 2 * pad - R) // stride + 1, (Wi + 2 * pad - S) // stride + 1
+    y = torch.empty(B, Ho, Wo, Co, dtype=torch.bfloat16, device=x.device)
+    M = B * Ho * Wo
+    acc = _accumulator(x.device, Co, "stats") if stat_shift is not None else None
+    _igemm(x, w, y, M, Hi, Wi, Ci, Ci, Ho, Wo, stride, Ho, Wo, 1, 0, 0, Co, Co, R * S * Ci, _fprop_taps(R, S, pad),
+           stat_acc=acc, stat_shift=stat_shift, tile=tile)
+    moments = _moments_from_acc(acc, Co, M) if acc is not None else None
+    return y, moments
+
+
+def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R: int, S: int, stride: int, pad: int,
+               addend: Optional[torch.Tensor] = None, mask_src: Optional[torch.Tensor] = None, tile: int = 0):
+    dy = _bf16c(dy, "conv_dgrad dy")
+    if wt is None:
+        raise ValueError("conv_dgrad: the hip backend needs the transposed weight copy wt[Cin,R,S,Cout]")
+    B, Hi, Wi, Ci = in_shape
+    _, Ho, Wo, Co = dy.shape
+    dx = torch.empty(B, Hi, Wi, Ci, dtype=torch.bfloat16, device=dy.device)
+    if addend is not None:
+        addend = _bf16c(addend, "conv_dgrad addend")
+    if mask_src is not None:
+        mask_src = _bf16c(mask_src, "conv_dgrad mask")
+    if stride == 1:
+        _igemm(dy, wt, dx, B * Hi * Wi, Ho, Wo, Co, Co, Hi, Wi, 1, Hi, Wi, 1, 0, 0, Ci, Ci, R * S * Co,
+               _dgrad_taps(R, S, pad, 1, 0, 0), addend=addend, mask=mask_src, tile=tile)
+        return dx
+    for ph in range(stride):
+        for pw in range(stride):
+            Hg = (Hi - ph + stride - 1) // stride
+            Wg = (Wi - pw + stride - 1) // stride
+            if Hg <= 0 or Wg <= 0:
+                continue
+            _igemm(dy, wt, dx, B * Hg * Wg, Ho, Wo, Co, Co, Hg, Wg, 1, Hi, Wi, stride, ph, pw, Ci, Ci, R * S * Co,
+                   _dgrad_taps(R, S, pad, stride, ph, pw), addend=addend, mask=mask_src, tile=tile)
+    return dx
+
+
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, R: int, S: int, stride: int, pad: int, dw: torch.Tensor,
+               tile: int = 0, target_blocks: int = 0) -> None:
+    x = _bf16c(x, "conv_wgrad x")
+    dy = _bf16c(dy, "conv_wgrad dy")
+    _f32c(dw, "conv_wgrad dw")
+    B, Hi, Wi, Ci = x.shape
+    _, Ho, Wo, Co = dy.shape
+    _wgrad(dy, x, dw, B * Ho * Wo, Hi, Wi, Ci, Ci, Ho, Wo, stride, Co, Co, R * S * Ci, _fprop_taps(R, S, pad),
+           tile=tile, target_blocks=target_blocks)
+
+
+def transpose_weights(w: torch.Tensor, wt: torch.Tensor) -> None:
+    Co, R, S, Ci = w.shape
+    _check(_lib.pdt_transpose_w(_p(w), _p(wt), Co, R * S, Ci, Co, _stream()), "pdt_transpose_w")
+
+
+# --------------------------------------------------------------------------- batch norm
+def bn_stats(y: torch.Tensor, shift: Optional[torch.Tensor] = None) -> torch.Tensor:
+    y = _bf16c(y, "bn_stats")
+    C = y.shape[-1]
+    rows = y.numel() // C
+    acc = _accumulator(y.device, C, "stats")
+    _check(_lib.pdt_bn_stats_accum(_p(y), _p(shift), _p(acc), rows, C, _stream()), "pdt_bn_stats_accum")
+    return _moments_from_acc(acc, C, rows)
+
+
+def bn_finalize(moments, inv_world: float, gamma, beta, running_mean, running_var, momentum: float, eps: float,
+                count: int):
+    C = gamma.numel()
+    out = torch.empty(4, C, dtype=torch.float32, device=gamma.device)
+    unbias = float(count) / float(max(count - 1, 1))
+    rc = _lib.pdt_bn_finalize(_p(moments), inv_world, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                              momentum, eps, unbias, _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), C, _stream())
+    _check(rc, "pdt_bn_finalize")
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps: float):
+    C = gamma.numel()
+    out = torch.empty(2, C, dtype=torch.float32, device=gamma.device)
+    rc = _lib.pdt_bn_eval_affine(_p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(out[0]), _p(out[1]),
+                                 C, _stream())
+    _check(rc, "pdt_bn_eval_affine")
+    return out[0], out[1]
+
+
+def bn_apply(y, scale, shift, residual, relu: bool):
+    y = _bf16c(y, "bn_apply y")
+    C = y.shape[-1]
+    out = torch.empty_like(y)
+    if residual is not None:
+        residual = _bf16c(residual, "bn_apply residual")
+    rc = _lib.pdt_bn_apply(_p(y), _p(scale), _p(shift), _p(residual), _p(out), y.numel() // C, C, int(bool(relu)),
+                           _stream())
+    _check(rc, "pdt_bn_apply")
+    return out
+
+
+def bn_bwd_reduce(g, y, mean, invstd, scale, shift, mask_src, mask_mode: int, dgamma=None, dbeta=None):
+    g = _bf16c(g, "bn_bwd_reduce g")
+    y = _bf16c(y, "bn_bwd_reduce y")
+    if mask_mode == MASK_TENSOR:
+        mask_src = _bf16c(mask_src, "bn_bwd_reduce mask")
+    C = y.shape[-1]
+    rows = y.numel() // C
+    acc = _accumulator(y.device, C, "bwd")
+    rc = _lib.pdt_bn_bwd_reduce_accum(_p(g), _p(y), _p(mask_src) if mask_mode == MASK_TENSOR else None, _p(mean),
+                                      _p(scale), _p(shift), _p(acc), rows, C, mask_mode, _stream())
+    _check(rc, "pdt_bn_bwd_reduce_accum")
+    sums = torch.empty(2, C, dtype=torch.float32, device=y.device)
+    _check(_lib.pdt_bn_bwd_sums(_p(acc), _p(invstd), _p(sums), _p(dgamma), _p(dbeta), C, _stream()), "pdt_bn_bwd_sums")
+    return sums
+
+
+def bn_bwd_elemt(g, y, mean, invstd, scale, shift, sums, inv_count: float, mask_src, mask_mode: int):
+    g = _bf16c(g, "bn_bwd_elemt g")
+    y = _bf16c(y, "bn_bwd_elemt y")
+    C = y.shape[-1]
+    dx = torch.empty_like(y)
+    rc = _lib.pdt_bn_bwd_elemt(_p(g), _p(y), _p(mask_src) if mask_mode == MASK_TENSOR else None, _p(mean), _p(invstd),
+                               _p(scale), _p(shift), _p(sums), inv_count, _p(dx), y.numel() // C, C, mask_mode,
+                               _stream())
+    _check(rc, "pdt_bn_bwd_elemt")
+    return dx
+
+
+# --------------------------------------------------------------------------- pooling
+def maxpool_fwd(x):
+    x = _bf16c(x, "maxpool_fwd")
+    B, H, W, C = x.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    out = torch.empty(B, Ho, Wo, C, dtype=torch.bfloat16, device=x.device)
+    idx = torch.empty(B, Ho, Wo, C, dtype=torch.uint8, device=x.device)
+    _check(_lib.pdt_maxpool_fwd(_p(x), _p(out), _p(idx), B, H, W, C, Ho, Wo, _stream()), "pdt_maxpool_fwd")
+    return out, idx
+
+
+def maxpool_bwd(dout, idx, in_shape):
+    dout = _bf16c(dout, "maxpool_bwd")
+    B, H, W, C = in_shape
+    _, Ho, Wo, _ = dout.shape
+    dx = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=dout.device)
+    _check(_lib.pdt_maxpool_bwd(_p(dout), _p(idx), _p(dx), B, H, W, C, Ho, Wo, _stream()), "pdt_maxpool_bwd")
+    return dx
+
+
+def avgpool_fwd(x):
+    x = _bf16c(x, "avgpool_fwd")
+    B, H, W, C = x.shape
+    out = torch.empty(B, C, dtype=torch.bfloat16, device=x.device)
+    _check(_lib.pdt_avgpool_fwd(_p(x), _p(out), B, H * W, C, _stream()), "pdt_avgpool_fwd")
+    return out
+
+
+def avgpool_bwd(dp, H: int, W: int):
+    dp = _bf16c(dp, "avgpool_bwd")
+    B, C = dp.shape
+    dx = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=dp.device)
+    _check(_lib.pdt_avgpool_bwd(_p(dp), _p(dx), B, H * W, C, _stream()), "pdt_avgpool_bwd")
+    return dx
+
+
+# --------------------------------------------------------------------------- classifier + loss
+_ONE_TAP = None
+
+
+def _one_tap() -> _Taps:
+    global _ONE_TAP
+    if _ONE_TAP is None:
+        _ONE_TAP = _Taps([0], [0], [0])
+    return _ONE_TAP
+
+
+def _npad(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+def prepare_fc(w: torch.Tensor) -> torch.Tensor:
+    """``w[N, K]`` -> zero-padded transposed copy ``wt[K, Npad]`` for the classifier's data gradient."""
+    w = _bf16c(w, "prepare_fc")
+    N, K = w.shape
+    wt = torch.empty(K, _npad(N), dtype=torch.bfloat16, device=w.device)
+    _check(_lib.pdt_transpose_w(_p(w), _p(wt), N, 1, K, _npad(N), _stream()), "pdt_transpose_w")
+    return wt
+
+
+def linear_fwd(a, w, bias):
+    a = _bf16c(a, "linear_fwd a")
+    w = _bf16c(w, "linear_fwd w")
+    B, K = a.shape
+    N = w.shape[0]
+    ld = _npad(N)
+    out = torch.empty(B, ld, dtype=torch.bfloat16, device=a.device)
+    _igemm(a, w, out, B, 1, 1, K, K, 1, 1, 1, 1, 1, 1, 0, 0, N, ld, K, _one_tap(), bias=bias)
+    return out[:, :N]
+
+
+def linear_bwd(a, dlogits, w, wt, dw, dbias):
+    a = _bf16c(a, "linear_bwd a")
+    B, K = a.shape
+    N = w.shape[0]
+    ld = dlogits.stride(0)
+    if dlogits.dtype != torch.bfloat16 or dlogits.stride(1) != 1 or ld % 64 != 0 or wt is None or wt.shape[1] != ld:
+        raise ValueError("linear_bwd: dlogits must be the padded bf16 buffer produced by softmax_ce")
+    da = torch.empty(B, K, dtype=torch.bfloat16, device=a.device)
+    _igemm(dlogits, wt, da, B, 1, 1, ld, ld, 1, 1, 1, 1, 1, 1, 0, 0, K, K, ld, _one_tap())
+    _wgrad(dlogits, a, dw, B, 1, 1, K, K, 1, 1, 1, N, ld, K, _one_tap())
+    _check(_lib.pdt_colsum_add(_p(dlogits), _p(dbias), B, N, ld, _stream()), "pdt_colsum_add")
+    return da
+
+
+def softmax_ce(logits, labels, grad_scale: float = 1.0):
+    if logits.dtype != torch.bfloat16 or logits.stride(1) != 1:
+        raise TypeError("softmax_ce: logits must be bf16 with unit column stride")
+    B, N = logits.shape
+    ld_out = _npad(N)
+    dlog = torch.empty(B, ld_out, dtype=torch.bfloat16, device=logits.device)
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    labels = labels if labels.dtype == torch.int64 else labels.long()
+    rc = _lib.pdt_softmax_ce(_p(logits), _p(labels.contiguous()), _p(dlog), _p(loss), B, N, logits.stride(0), ld_out,
+                             grad_scale, _stream())
+    _check(rc, "pdt_softmax_ce")
+    return loss[0], dlog[:, :N]
+
+
+def ce_metrics(logits, labels):
+    if logits.dtype != torch.bfloat16 or logits.stride(1) != 1:
+        raise TypeError("ce_metrics: logits must be bf16 with unit column stride")
+    B, N = logits.shape
+    out = torch.empty(4, dtype=torch.float32, device=logits.device)
+    labels = labels if labels.dtype == torch.int64 else labels.long()
+    rc = _lib.pdt_ce_metrics(_p(logits), _p(labels.contiguous()), _p(out), B, N, logits.stride(0), _stream())
+    _check(rc, "pdt_ce_metrics")
+    return out
+
+
+# --------------------------------------------------------------------------- optimizer
+def sgd_step(p, g, m, pc, lr: float, momentum: float, weight_decay: float, grad_scale: float, nesterov: bool = False,
+             dampening: float = 0.0, first_step: bool = False) -> None:
+    n = p.numel()
+    rc = _lib.pdt_sgd_step(_p(p), _p(g), _p(m), _p(pc), n, lr, momentum, weight_decay, grad_scale, dampening,
+                           int(bool(nesterov)), int(bool(first_step)), _stream())
+    _check(rc, "pdt_sgd_step")

@@ -41,15 +41,19 @@ def _w_oihw(w: torch.Tensor) -> torch.Tensor:
     return w.permute(0, 3, 1, 2)
 
 
-def channel_moments(y32: torch.Tensor) -> torch.Tensor:
-    """``[2, C]``: per-channel ``E[y]`` and ``E[y^2]`` over all leading dims.
+def channel_moments(y32: torch.Tensor, shift: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``[2, C]``: per-channel SHIFTED moments ``E[y - s]`` and ``E[(y - s)^2]``.
 
-    The second moment is formed as ``var + mean^2`` from a centred variance, so the only
-    cancellation left is the final ``E[y^2] - mean^2`` in :func:`bn_finalize`.  Moments (rather
-    than mean/variance) are what ranks exchange for SyncBatchNorm: with equal per-rank counts
-    the global moments are the plain average of the local ones, i.e. ONE sum all-reduce.
+    ``s`` is a per-channel shift (the BatchNorm running mean; zero when ``None``).  Shifted
+    moments are what ranks exchange for SyncBatchNorm: running means are identical on all
+    ranks and per-rank counts are equal, so the global moments are the plain average of the
+    local ones -- ONE sum all-reduce of ``2C`` floats -- and the variance
+    ``E[(y-s)^2] - E[y-s]^2`` only suffers cancellation if the batch mean is many standard
+    deviations away from the running mean.
     """
     flat = y32.reshape(-1, y32.shape[-1])
+    if shift is not None:
+        flat = flat - shift
     var, mean = torch.var_mean(flat, dim=0, unbiased=False)
     return torch.stack([mean, var + mean * mean])
 
@@ -74,8 +78,8 @@ def prepare_stem_weight(w: torch.Tensor) -> torch.Tensor:
     return w
 
 
-def stem_fprop(x0: torch.Tensor, w: torch.Tensor, want_stats: bool):
-    return conv_fprop(x0, w, 7, 7, 2, 3, want_stats)
+def stem_fprop(x0: torch.Tensor, w: torch.Tensor, stat_shift: Optional[torch.Tensor] = None):
+    return conv_fprop(x0, w, 7, 7, 2, 3, stat_shift)
 
 
 def stem_wgrad(x0: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) -> None:
@@ -84,16 +88,18 @@ def stem_wgrad(x0: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) -> None:
 
 # ---------------------------------------------------------------------------- convolution
 def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pad: int,
-               want_stats: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+               stat_shift: Optional[torch.Tensor] = None, **_) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """``y = conv(x, w)``; when ``stat_shift`` is given also the shifted per-channel moments of
+    the fp32 result (see :func:`channel_moments`)."""
     y32 = F.conv2d(_nchw(x.float()), _w_oihw(w.float()), None, stride, pad)
     y32 = _nhwc(y32)
-    stats = channel_moments(y32) if want_stats else None
+    stats = channel_moments(y32, stat_shift) if stat_shift is not None else None
     return y32.to(x.dtype), stats
 
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: Optional[torch.Tensor], in_shape, R: int, S: int,
                stride: int, pad: int, addend: Optional[torch.Tensor] = None,
-               mask_src: Optional[torch.Tensor] = None) -> torch.Tensor:
+               mask_src: Optional[torch.Tensor] = None, **_) -> torch.Tensor:
     """``dx = conv_transpose(dy, w) [+ addend * (mask_src > 0)]`` ; ``in_shape = (B, Hi, Wi, Ci)``."""
     B, Hi, Wi, Ci = in_shape
     dx = torch.nn.grad.conv2d_input((B, Ci, Hi, Wi), _w_oihw(w.float()), _nchw(dy.float()), stride, pad)
@@ -106,7 +112,8 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: Optional[torch.Tensor], in
     return dx.to(dy.dtype)
 
 
-def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, R: int, S: int, stride: int, pad: int, dw: torch.Tensor) -> None:
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, R: int, S: int, stride: int, pad: int, dw: torch.Tensor,
+               **_) -> None:
     """``dw[Cout, R, S, Cin] += x (*) dy`` (fp32 accumulate into the flat gradient buffer)."""
     Co, Ci = dy.shape[-1], x.shape[-1]
     g = torch.nn.grad.conv2d_weight(_nchw(x.float()), (Co, Ci, R, S), _nchw(dy.float()), stride, pad)
@@ -120,23 +127,24 @@ def transpose_weights(w: torch.Tensor, wt: Optional[torch.Tensor]) -> None:
 
 
 # ---------------------------------------------------------------------------- batch norm
-def bn_stats(y: torch.Tensor) -> torch.Tensor:
-    """Stand-alone per-channel moments ``[E[y], E[y^2]]`` of an NHWC tensor."""
-    return channel_moments(y.float())
+def bn_stats(y: torch.Tensor, shift: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Stand-alone shifted per-channel moments of an NHWC tensor."""
+    return channel_moments(y.float(), shift)
 
 
 def bn_finalize(moments: torch.Tensor, inv_world: float, gamma: torch.Tensor, beta: torch.Tensor,
                 running_mean: torch.Tensor, running_var: torch.Tensor, momentum: float, eps: float, count: int):
     """Summed moments -> ``(scale, shift, mean, invstd)``; updates running stats in place.
 
-    ``moments`` is the (all-reduced) SUM over ranks of the local ``[E[y], E[y^2]]`` and
-    ``inv_world = 1 / world_size`` turns it into the global moments.  ``scale = gamma *
-    invstd``, ``shift = beta - mean * scale``.  The running variance uses the unbiased
-    estimate with the GLOBAL element count ``count``, as ``SyncBatchNorm`` does
-    (``torch/nn/modules/_functions.py:106-115``).
+    ``moments`` is the (all-reduced) SUM over ranks of the local moments shifted by
+    ``running_mean`` (its value BEFORE this update) and ``inv_world = 1 / world_size`` turns
+    it into the global moments.  ``scale = gamma * invstd``, ``shift = beta - mean * scale``.
+    The running variance uses the unbiased estimate with the GLOBAL element count
+    ``count``, as ``SyncBatchNorm`` does (``torch/nn/modules/_functions.py:106-115``).
     """
-    mean = moments[0] * inv_world
-    var = (moments[1] * inv_world - mean * mean).clamp_min(0.0)
+    m0 = moments[0] * inv_world
+    mean = running_mean + m0
+    var = (moments[1] * inv_world - m0 * m0).clamp_min(0.0)
     invstd = torch.rsqrt(var + eps)
     scale = gamma * invstd
     shift = beta - mean * scale

@@ -1,0 +1,232 @@
+"""GPU tier: every HIP kernel against the plain-PyTorch fp32 reference of the same op."""
+import pytest
+import torch
+
+from pytorch_distributed_training_amd.ops import ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from pytorch_distributed_training_amd.ops import hip as hip_ops
+    return hip_ops
+
+
+def rnd(*shape, device, scale=1.0, dtype=torch.bfloat16):
+    return (torch.randn(*shape, device=device) * scale).to(dtype)
+
+
+def rel_err(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-6)).item()
+
+
+# 23 distinct ResNet-50 convolution shapes: (Cin, Cout, k, stride, pad, H)
+R50_SHAPES = [
+    (64, 64, 1, 1, 0, 56), (64, 64, 3, 1, 1, 56), (64, 256, 1, 1, 0, 56), (256, 64, 1, 1, 0, 56),
+    (256, 128, 1, 1, 0, 56), (128, 128, 3, 2, 1, 56), (128, 512, 1, 1, 0, 28), (256, 512, 1, 2, 0, 56),
+    (512, 128, 1, 1, 0, 28), (128, 128, 3, 1, 1, 28), (512, 256, 1, 1, 0, 28), (256, 256, 3, 2, 1, 28),
+    (256, 1024, 1, 1, 0, 14), (512, 1024, 1, 2, 0, 28), (1024, 256, 1, 1, 0, 14), (256, 256, 3, 1, 1, 14),
+    (1024, 512, 1, 1, 0, 14), (512, 512, 3, 2, 1, 14), (512, 2048, 1, 1, 0, 7), (1024, 2048, 1, 2, 0, 14),
+    (2048, 512, 1, 1, 0, 7), (512, 512, 3, 1, 1, 7),
+]
+
+
+@pytest.mark.parametrize("shape", R50_SHAPES)
+@pytest.mark.parametrize("B", [1, 5])
+def test_conv_fprop_dgrad_wgrad(hip, device, shape, B):
+    Ci, Co, k, stride, pad, H = shape
+    torch.manual_seed(Ci * 7 + Co + k + stride + B)
+    x = rnd(B, H, H, Ci, device=device)
+    w = rnd(Co, k, k, Ci, device=device, scale=(2.0 / (k * k * Ci)) ** 0.5)
+    shift = torch.randn(Co, device=device) * 0.1
+    y, mom = hip.conv_fprop(x, w, k, k, stride, pad, shift)
+    y_ref, mom_ref = ref.conv_fprop(x, w, k, k, stride, pad, shift)
+    assert rel_err(y, y_ref) < 1.5e-2
+    assert torch.allclose(mom, mom_ref, rtol=2e-3, atol=2e-3)
+
+    dy = rnd(*y.shape, device=device)
+    wt = torch.empty(Ci, k, k, Co, dtype=torch.bfloat16, device=device)
+    hip.transpose_weights(w, wt)
+    assert torch.equal(wt, w.permute(3, 1, 2, 0).contiguous())
+    addend = rnd(*x.shape, device=device)
+    mask = rnd(*x.shape, device=device)
+    for a, m in ((None, None), (addend, None), (addend, mask)):
+        dx = hip.conv_dgrad(dy, w, wt, tuple(x.shape), k, k, stride, pad, a, m)
+        dx_ref = ref.conv_dgrad(dy, w, None, tuple(x.shape), k, k, stride, pad, a, m)
+        assert rel_err(dx, dx_ref) < 1.5e-2
+
+    dw = torch.zeros(Co, k, k, Ci, dtype=torch.float32, device=device)
+    dw_ref = torch.zeros_like(dw)
+    hip.conv_wgrad(x, dy, k, k, stride, pad, dw)
+    ref.conv_wgrad(x, dy, k, k, stride, pad, dw_ref)
+    assert rel_err(dw, dw_ref) < 5e-3
+    # accumulation semantics
+    hip.conv_wgrad(x, dy, k, k, stride, pad, dw)
+    assert rel_err(dw, 2 * dw_ref) < 5e-3
+
+
+def test_conv_identity_asymmetric(hip, device):
+    """A = identity weights, asymmetric data: catches a row/column swap in the C write."""
+    B, H, C = 2, 9, 64
+    x = torch.arange(B * H * H * C, device=device, dtype=torch.float32).reshape(B, H, H, C)
+    x = ((x % 251) - 125).to(torch.bfloat16)
+    w = torch.eye(C, device=device).reshape(C, 1, 1, C).to(torch.bfloat16)
+    y, _ = hip.conv_fprop(x, w, 1, 1, 1, 0, None)
+    assert torch.equal(y, x)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 5])
+def test_conv_tiles(hip, device, tile):
+    torch.manual_seed(tile)
+    x = rnd(3, 14, 14, 128, device=device)
+    w = rnd(192, 3, 3, 128, device=device, scale=0.03)
+    y = hip.conv_fprop(x, w, 3, 3, 1, 1, None, tile=tile)[0]
+    y_ref = ref.conv_fprop(x, w, 3, 3, 1, 1, None)[0]
+    assert rel_err(y, y_ref) < 1.5e-2
+
+
+@pytest.mark.parametrize("tile", [1, 2, 4])
+def test_wgrad_tiles(hip, device, tile):
+    torch.manual_seed(tile)
+    x = rnd(3, 14, 14, 128, device=device)
+    dy = rnd(3, 14, 14, 192, device=device)
+    dw = torch.zeros(192, 3, 3, 128, dtype=torch.float32, device=device)
+    dw_ref = torch.zeros_like(dw)
+    hip.conv_wgrad(x, dy, 3, 3, 1, 1, dw, tile=tile)
+    ref.conv_wgrad(x, dy, 3, 3, 1, 1, dw_ref)
+    assert rel_err(dw, dw_ref) < 5e-3
+
+
+@pytest.mark.parametrize("fmt", ["float_nchw", "uint8_nhwc"])
+@pytest.mark.parametrize("B,H", [(2, 64), (3, 224)])
+def test_stem(hip, device, fmt, B, H):
+    torch.manual_seed(B + H)
+    mean = torch.tensor((0.485, 0.456, 0.406), device=device)
+    std = torch.tensor((0.229, 0.224, 0.225), device=device)
+    if fmt == "uint8_nhwc":
+        img = torch.randint(0, 256, (B, H, H, 3), device=device, dtype=torch.uint8)
+    else:
+        img = torch.randn(B, 3, H, H, device=device)
+    x0 = hip.input_transform(img, mean, std, torch.bfloat16)
+    x0_ref = ref.input_transform(img, mean, std, torch.bfloat16)
+    assert torch.equal(x0[:, 3:3 + H, 3:3 + H, :3], x0_ref)
+    assert x0[:, :3].abs().sum() == 0 and x0[..., 3].abs().sum() == 0
+    w = rnd(64, 7, 7, 3, device=device, scale=0.1)
+    wp = hip.prepare_stem_weight(w)
+    shift = torch.zeros(64, device=device)
+    y, mom = hip.stem_fprop(x0, wp, shift)
+    y_ref, mom_ref = ref.stem_fprop(x0_ref, w, shift)
+    assert rel_err(y, y_ref) < 1.5e-2
+    assert torch.allclose(mom, mom_ref, rtol=2e-3, atol=2e-3)
+    dy = rnd(*y.shape, device=device)
+    dw = torch.zeros(64, 7, 7, 3, dtype=torch.float32, device=device)
+    dw_ref = torch.zeros_like(dw)
+    hip.stem_wgrad(x0, dy, dw)
+    ref.stem_wgrad(x0_ref, dy, dw_ref)
+    assert rel_err(dw, dw_ref) < 5e-3
+
+
+@pytest.mark.parametrize("C,rows", [(64, 5000), (256, 777), (2048, 98), (128, 64 * 3136)])
+def test_bn_family(hip, device, C, rows):
+    torch.manual_seed(C + rows)
+    y = (torch.randn(rows, C, device=device) * 1.5 + torch.randn(C, device=device)).to(torch.bfloat16).view(1, rows, 1, C)
+    shift = torch.randn(C, device=device) * 0.2
+    mom = hip.bn_stats(y, shift)
+    mom_ref = ref.bn_stats(y, shift)
+    assert torch.allclose(mom, mom_ref, rtol=1e-3, atol=1e-3)
+
+    gamma = torch.rand(C, device=device) + 0.5
+    beta = torch.randn(C, device=device) * 0.1
+    rm, rv = shift.clone(), torch.ones(C, device=device)
+    rm_r, rv_r = shift.clone(), torch.ones(C, device=device)
+    sc, sh, mu, istd = hip.bn_finalize(mom_ref.clone(), 1.0, gamma, beta, rm, rv, 0.1, 1e-5, rows)
+    sc_r, sh_r, mu_r, istd_r = ref.bn_finalize(mom_ref.clone(), 1.0, gamma, beta, rm_r, rv_r, 0.1, 1e-5, rows)
+    for a, b in ((sc, sc_r), (sh, sh_r), (mu, mu_r), (istd, istd_r), (rm, rm_r), (rv, rv_r)):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+    esc, esh = hip.bn_eval_affine(gamma, beta, rm, rv, 1e-5)
+    esc_r, esh_r = ref.bn_eval_affine(gamma, beta, rm, rv, 1e-5)
+    assert torch.allclose(esc, esc_r, rtol=1e-5) and torch.allclose(esh, esh_r, rtol=1e-4, atol=1e-6)
+
+    res = rnd(1, rows, 1, C, device=device)
+    for r, relu in ((None, True), (res, True), (None, False), (res, False)):
+        out = hip.bn_apply(y, sc_r, sh_r, r, relu)
+        out_ref = ref.bn_apply(y, sc_r, sh_r, r, relu)
+        assert rel_err(out, out_ref) < 1e-2
+
+    g = rnd(1, rows, 1, C, device=device)
+    msrc = rnd(1, rows, 1, C, device=device)
+    for mode, m in ((ref.MASK_NONE, None), (ref.MASK_TENSOR, msrc), (ref.MASK_RECOMPUTE, None)):
+        dg, db = torch.zeros(C, device=device), torch.zeros(C, device=device)
+        dg_r, db_r = torch.zeros(C, device=device), torch.zeros(C, device=device)
+        sums = hip.bn_bwd_reduce(g, y, mu_r, istd_r, sc_r, sh_r, m, mode, dg, db)
+        sums_ref = ref.bn_bwd_reduce(g, y, mu_r, istd_r, sc_r, sh_r, m, mode, dg_r, db_r)
+        tol = 2e-3 * max(rows ** 0.5, 1.0)
+        assert torch.allclose(sums, sums_ref, rtol=2e-3, atol=tol)
+        assert torch.allclose(dg, dg_r, rtol=2e-3, atol=tol) and torch.allclose(db, db_r, rtol=2e-3, atol=tol)
+        dx = hip.bn_bwd_elemt(g, y, mu_r, istd_r, sc_r, sh_r, sums_ref, 1.0 / rows, m, mode)
+        dx_ref = ref.bn_bwd_elemt(g, y, mu_r, istd_r, sc_r, sh_r, sums_ref, 1.0 / rows, m, mode)
+        assert rel_err(dx, dx_ref) < 1.5e-2
+
+
+@pytest.mark.parametrize("B,H,C", [(2, 112, 64), (3, 30, 64), (1, 8, 128)])
+def test_pooling(hip, device, B, H, C):
+    torch.manual_seed(B + H)
+    x = torch.relu(rnd(B, H, H, C, device=device))       # many exact ties at 0, like post-ReLU activations
+    out, idx = hip.maxpool_fwd(x)
+    out_ref, idx_ref = ref.maxpool_fwd(x)
+    assert torch.equal(out, out_ref)
+    dout = rnd(*out.shape, device=device)
+    dx = hip.maxpool_bwd(dout, idx, tuple(x.shape))
+    dx_ref = ref.maxpool_bwd(dout, idx_ref, tuple(x.shape))
+    assert rel_err(dx, dx_ref) < 1e-2
+    p = hip.avgpool_fwd(x)
+    assert rel_err(p, ref.avgpool_fwd(x)) < 1e-2
+    dp = rnd(B, C, device=device)
+    assert rel_err(hip.avgpool_bwd(dp, H, H), ref.avgpool_bwd(dp, H, H)) < 1e-2
+
+
+@pytest.mark.parametrize("B,K,N", [(64, 2048, 1000), (7, 512, 10)])
+def test_classifier_and_loss(hip, device, B, K, N):
+    torch.manual_seed(B + N)
+    a = rnd(B, K, device=device)
+    w = rnd(N, K, device=device, scale=0.02)
+    bias = torch.randn(N, device=device) * 0.1
+    logits = hip.linear_fwd(a, w, bias)
+    logits_ref = ref.linear_fwd(a, w, bias)
+    assert rel_err(logits, logits_ref) < 1.5e-2
+    labels = torch.randint(0, N, (B,), device=device)
+    logits[0, labels[0]] += 30.0          # one extreme row
+    loss, dlog = hip.softmax_ce(logits, labels, 1.0)
+    loss_ref, dlog_ref = ref.softmax_ce(logits, labels, 1.0)
+    assert abs(loss.item() - loss_ref.item()) < 2e-3 * max(1.0, abs(loss_ref.item()))
+    assert (dlog.float() - dlog_ref.float()).abs().max().item() < 2e-2 / B + 1e-4
+    met = hip.ce_metrics(logits, labels)
+    met_ref = ref.ce_metrics(logits, labels)
+    assert torch.allclose(met, met_ref, rtol=2e-3, atol=1e-2)
+    wt = hip.prepare_fc(w)
+    dw, db = torch.zeros(N, K, device=device), torch.zeros(N, device=device)
+    dw_r, db_r = torch.zeros(N, K, device=device), torch.zeros(N, device=device)
+    da = hip.linear_bwd(a, dlog, w, wt, dw, db)
+    da_ref = ref.linear_bwd(a, dlog, w, None, dw_r, db_r)
+    assert rel_err(da, da_ref) < 2e-2
+    assert rel_err(dw, dw_r) < 1e-2 and rel_err(db, db_r) < 1e-2
+
+
+def test_fused_sgd_matches_torch(hip, device):
+    torch.manual_seed(0)
+    n = 64 * 1000
+    p0 = torch.randn(n, device=device)
+    p = p0.clone(); m = torch.zeros(n, device=device); pc = torch.zeros(n, device=device, dtype=torch.bfloat16)
+    tp = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([tp], lr=0.1, momentum=0.9, weight_decay=1e-4)
+    for step in range(100):
+        grad = torch.randn(n, device=device)
+        g = grad.clone() * 4.0
+        hip.sgd_step(p, g, m, pc, 0.1, 0.9, 1e-4, 0.25, False, 0.0, step == 0)
+        assert g.abs().sum() == 0
+        tp.grad = grad.clone()
+        opt.step()
+    assert torch.allclose(p, tp.data, rtol=1e-4, atol=1e-5)
+    assert torch.equal(pc, p.to(torch.bfloat16))
