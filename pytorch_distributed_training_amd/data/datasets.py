@@ -67,10 +67,10 @@ class TrainTransform:
         w, h = img.size
         x, y, cw, ch = _random_resized_crop_box(w, h, self.rng)
         img = img.resize((self.size, self.size), Image.BILINEAR, box=(x, y, x + cw, y + ch))
-        arr = np.asarray(img, dtype=np.uint8)
+        arr = np.array(img, dtype=np.uint8)
         if self.rng.random() < 0.5:
-            arr = arr[:, ::-1, :]
-        return np.ascontiguousarray(arr)
+            arr = np.ascontiguousarray(arr[:, ::-1, :])
+        return arr
 
 
 class ValTransform:
@@ -91,7 +91,7 @@ class ValTransform:
         img = img.resize((nw, nh), Image.BILINEAR)
         left, top = (nw - self.size) // 2, (nh - self.size) // 2
         img = img.crop((left, top, left + self.size, top + self.size))
-        return np.ascontiguousarray(np.asarray(img, dtype=np.uint8))
+        return np.array(img, dtype=np.uint8)
 
 
 def to_output_format(arr_hwc_u8: np.ndarray, fmt: str) -> torch.Tensor:

@@ -19,13 +19,22 @@ from torch.utils.data import DataLoader, Dataset
 from ..parallel.sampler import DistributedShardSampler
 
 
-def make_iter_dataloader(loader: DataLoader, start_epoch: int = 0) -> Iterator:
-    """Endless ``(img, label)`` generator; advances the sampler's epoch at every restart."""
+def make_iter_dataloader(loader: DataLoader, start_epoch: int = 0, skip_batches: int = 0) -> Iterator:
+    """Endless ``(img, label)`` generator; advances the sampler's epoch at every restart.
+
+    ``start_epoch`` / ``skip_batches`` position the stream when training resumes from a
+    checkpoint taken in the middle of an epoch (the skipped samples are never loaded).
+    """
     epoch = start_epoch
+    skip = skip_batches * (loader.batch_size or 1)
     while True:
         sampler = getattr(loader, "sampler", None)
         if hasattr(sampler, "set_epoch"):
-            sampler.set_epoch(epoch)
+            try:
+                sampler.set_epoch(epoch, skip)
+            except TypeError:          # torch's DistributedSampler: no mid-epoch positioning
+                sampler.set_epoch(epoch)
+        skip = 0
         for batch in loader:
             yield batch
         epoch += 1

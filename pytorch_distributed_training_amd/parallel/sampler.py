@@ -34,6 +34,7 @@ class DistributedShardSampler(Sampler):
         self.drop_last = drop_last
         self.pad = pad
         self.epoch = 0
+        self.skip = 0            # samples of the NEXT iteration already consumed (mid-epoch resume)
         if drop_last:
             self.num_samples = self.n // self.world
         elif pad:
@@ -41,8 +42,11 @@ class DistributedShardSampler(Sampler):
         else:
             self.num_samples = len(range(self.rank, self.n, self.world))
 
-    def set_epoch(self, epoch: int) -> None:
+    def set_epoch(self, epoch: int, skip_samples: int = 0) -> None:
+        """Select the epoch's permutation; ``skip_samples`` drops that many leading samples of
+        this rank's shard once (resuming in the middle of an epoch)."""
         self.epoch = int(epoch)
+        self.skip = max(int(skip_samples), 0)
 
     def _permutation(self):
         if self.shuffle:
@@ -60,7 +64,11 @@ class DistributedShardSampler(Sampler):
             if total > len(idx) and len(idx) > 0:
                 reps = math.ceil((total - len(idx)) / len(idx))
                 idx = idx + (idx * reps)[: total - len(idx)]
-        return iter(idx[self.rank::self.world])
+        shard = idx[self.rank::self.world]
+        if self.skip:
+            shard = shard[self.skip:]
+            self.skip = 0
+        return iter(shard)
 
     def __len__(self) -> int:
         return self.num_samples

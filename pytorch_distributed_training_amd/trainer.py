@@ -150,8 +150,9 @@ class Trainer:
     def run(self) -> None:
         tr = self.cfg["training"]
         train_iters = tr["train_iters"]
-        start_epoch = self.iter // max(len(self.train_loader), 1)
-        batches = DevicePrefetcher(make_iter_dataloader(self.train_loader, start_epoch), self.device)
+        per_epoch = max(len(self.train_loader), 1)
+        batches = DevicePrefetcher(
+            make_iter_dataloader(self.train_loader, self.iter // per_epoch, self.iter % per_epoch), self.device)
         debug_every = self.cfg["runtime"].get("debug_sync_check", 0)
         fault_iter = int(os.environ.get("FAULT_INJECT_ITER", "-1"))
         fault_rank = int(os.environ.get("FAULT_INJECT_RANK", "0"))
