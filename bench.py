@@ -79,7 +79,7 @@ def main() -> int:
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 or args.gpus > 1:
+    if world > 1 or args.gpus > 1 or dist_env.env_launch_detected():
         if world != args.gpus:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU with "
                   "torch.distributed.run", file=sys.stderr)
@@ -155,9 +155,13 @@ def main() -> int:
                 "parallelism": f"dp{info.world_size}" + ("+syncbn" if (args.sync_bn and info.world_size > 1) else ""),
                 "engine": args.engine, "optimizer": "SGD momentum 0.9 wd 1e-4", "final_loss": round(final_loss, 4),
                 "peak_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
+                "grad_buckets_reduced_per_step": (
+                    engine.model.reducer.stats["launched"] // max(args.steps + args.warmup, 1)
+                    if args.engine == "native" else None),
+                "sync_bn_active": bool(engine.model.sync_bn) if args.engine == "native" else None,
             },
         }), flush=True)
-    if info.distributed:
+    if dist.is_initialized():
         dist_env.shutdown()
     return 0
 

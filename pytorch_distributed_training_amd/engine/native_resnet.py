@@ -25,6 +25,7 @@ program is exercised by the CPU/gloo tests and checked against the eager model
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -77,8 +78,10 @@ class NativeResNet:
         self.ops = ops
         self.dtype = compute_dtype
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.sync_bn = bool(sync_bn) and self.world > 1
+        initialized = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if initialized else 1
+        forced = initialized and os.environ.get("PDT_FORCE_COLLECTIVES") == "1"   # debug: see GradReducer
+        self.sync_bn = bool(sync_bn) and (self.world > 1 or forced)
         self.bn_momentum = bn_momentum
         self.bn_eps = bn_eps
         self.training = True

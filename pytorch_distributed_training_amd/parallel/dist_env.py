@@ -63,7 +63,8 @@ def init_distributed(backend: str, dist_url: Optional[str], world_size: int, ran
     if backend == "nccl" and not (torch.cuda.device_count() > 0 and torch.cuda.is_available()):
         backend = "gloo"          # no GPU visible: CPU plumbing path
     device = pick_device(local_rank, backend)
-    if world_size > 1 and not dist.is_initialized():
+    forced = os.environ.get("PDT_FORCE_COLLECTIVES") == "1"      # debug: one-rank group, see GradReducer
+    if (world_size > 1 or forced) and not dist.is_initialized():
         kwargs = dict(backend=backend, world_size=world_size, rank=rank,
                       timeout=datetime.timedelta(seconds=timeout_s))
         if dist_url and dist_url != "env://":

@@ -22,6 +22,7 @@ Design for an xGMI mesh of MI355X GPUs:
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -34,8 +35,11 @@ class GradReducer:
         self.flat = flat_grad
         self.buckets = list(buckets)
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.enabled = self.world > 1
+        initialized = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if initialized else 1
+        # PDT_FORCE_COLLECTIVES=1 issues the collectives even in a one-rank group (debug: drives
+        # the RCCL / stream / event path on a single GPU).
+        self.enabled = self.world > 1 or (initialized and os.environ.get("PDT_FORCE_COLLECTIVES") == "1")
         self.overlap = overlap
         self.compress_bf16 = compress_bf16
         self.is_cuda = flat_grad.is_cuda
