@@ -56,6 +56,8 @@ def main() -> int:
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--wtile", type=int, default=0)
     ap.add_argument("--target-blocks", type=int, default=0)
+    ap.add_argument("--atomic-mb", type=int, default=0)
+    ap.add_argument("--stats", type=int, default=1)
     args = ap.parse_args()
     from pytorch_distributed_training_amd.ops import hip
 
@@ -85,7 +87,7 @@ def main() -> int:
         dyt = dy.permute(0, 3, 1, 2)
         for op in ops:
             if op == "fprop":
-                fn = lambda: hip.conv_fprop(x, w, k, k, stride, pad, shift, tile=args.tile)
+                fn = lambda: hip.conv_fprop(x, w, k, k, stride, pad, shift if args.stats else None, tile=args.tile)
                 ideal = xb + yb + wb
                 ref = lambda: torch.nn.functional.conv2d(xt, wtch, None, stride, pad)
             elif op == "dgrad":
@@ -94,7 +96,7 @@ def main() -> int:
                 ref = lambda: torch.nn.grad.conv2d_input(xt.shape, wtch, dyt, stride, pad)
             else:
                 fn = lambda: hip.conv_wgrad(x, dy, k, k, stride, pad, dw, tile=args.wtile,
-                                            target_blocks=args.target_blocks)
+                                            target_blocks=args.target_blocks, atomic_budget_mb=args.atomic_mb)
                 ideal = xb + yb + dw.numel() * 4
                 ref = lambda: torch.nn.grad.conv2d_weight(xt, wtch.shape, dyt, stride, pad)
             t = timeit(fn)

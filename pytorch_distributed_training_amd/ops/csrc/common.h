@@ -34,6 +34,22 @@ __device__ __forceinline__ bf16x8 zero_bf16x8() {
     return z;
 }
 
+// Buffer (SRD-based) 16-byte load: the descriptor carries the tensor size, and a byte offset at
+// or beyond it makes the hardware return zeros -- a branch-free, select-free way to zero-fill
+// padding / out-of-tile lanes.  Branch-free loads also let the compiler count outstanding
+// loads (s_waitcnt vmcnt(N)) instead of draining the queue at every conditional.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#define PDT_OOB_OFFSET 0x7ffffff0u
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ bf16x8 buf_ld_bf16x8(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    union { u32x4 u; bf16x8 v; } cvt;
+    cvt.u = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+    return cvt.v;
+}
+
 // Sum over the 64 lanes of a wave (all lanes get the result).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

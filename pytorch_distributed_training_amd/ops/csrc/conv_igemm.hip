@@ -14,18 +14,25 @@
 //   * the classifier GEMM and its data gradient                 (1x1 "images").
 //
 // Tiling: 256 threads = 4 waves; block tile BM x BN, K step BK (one tap, BK channels).  Global
-// loads are 16 B per lane, staged through registers into double-buffered LDS (loads for step
-// k+1 are issued before the MFMAs of step k and written to LDS after them: one barrier per
-// step).  LDS rows are BK bf16 long; the 16-byte chunk index is XOR-swizzled with the row so
+// loads are 16 B per lane, staged through two register sets into double-buffered LDS: the
+// loads for step k+2 are issued before the MFMAs of step k and written to LDS after the MFMAs
+// of step k+1 (two compute phases of latency cover, one barrier per step).  LDS rows are BK bf16 long; the 16-byte chunk index is XOR-swizzled with the row so
 // the ds_read_b128 fragment reads of the 16x16x32 operand layout (lane l: row l&15, k-chunk
-// l>>4) are bank-conflict free.  Workgroup ids are remapped so that each XCD's L2 sees a
-// contiguous range of tiles that share activation rows.
+// l>>4) are bank-conflict free.  Workgroups are persistent (one grid-full of resident blocks,
+// each looping over tiles): the first loads of a block's next tile are issued before the
+// epilogue of the current one, which matters most for the 1x1 layers with one or two K steps.
+// Tile ids are remapped so that each XCD's L2 sees a contiguous range of tiles that share
+// activation rows.
 //
-// Epilogue (through an fp32 LDS image of the tile, so global stores are full 16-B vectors):
-//   * optional per-channel bias,
+// The MFMA operands are swapped (weights on the "A" side), so a lane's four accumulator
+// registers are four CONSECUTIVE CHANNELS of one pixel.  Epilogue:
+//   * optional per-channel bias (in registers),
+//   * the tile goes to LDS as bf16 with 8-byte writes and leaves as full 16-byte vectors,
 //   * optional "out += addend [* (mask > 0)]"  (residual-gradient accumulation of a block),
-//   * optional BatchNorm statistics: per-channel sum(v - s) and sum((v - s)^2) over the tile's
-//     valid rows, added with float atomics to a replicated accumulator (see reduce.hip).
+//   * optional BatchNorm statistics: in the output loop every thread keeps meeting the same 8
+//     channels, so per-channel sum(v - s) and sum((v - s)^2) over the tile's valid rows are
+//     accumulated for free on the values being stored, reduced across threads through LDS and
+//     added with float atomics to a replicated accumulator (see reduce.hip).
 #include "common.h"
 
 #define NREP 16
@@ -41,15 +48,23 @@ struct IgemmParams {
     float* stat_acc;
     const float* stat_shift;
     long long M;
+    unsigned in_bytes, wgt_bytes;      // sizes of the input / weight tensors (buffer descriptors)
     int Hi, Wi, pix_stride, Ci;
     int Hg, Wg, IS;
     int Ho, Wo, OS, oy0, ox0;
     int N, ldo, wrow, T;
     int simple_out;
-    signed char offy[MAX_TAPS];
-    signed char offx[MAX_TAPS];
-    unsigned short widx[MAX_TAPS];
+    // one 32-bit word per tap: offy (int8) | offx (int8) << 8 | widx (uint16) << 16.  Sub-dword
+    // entries would be fetched with VECTOR loads (no scalar byte loads on gfx9), whose waits
+    // drain the tile prefetches; a dword indexed by a wave-uniform tap is one s_load_dword.
+    int taps[MAX_TAPS];
 };
+
+__device__ __forceinline__ void unpack_tap(int w, int& oy, int& ox, int& widx) {
+    oy = (int)(signed char)(w & 0xff);
+    ox = (int)(signed char)((w >> 8) & 0xff);
+    widx = (w >> 16) & 0xffff;
+}
 
 template <int BK>
 __device__ __forceinline__ int swz_chunk(int row, int chunk) {
@@ -68,86 +83,92 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     constexpr int KS = BK / 32;
     constexpr int RB = BK * 2;            // LDS row bytes
     constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB;
-    constexpr int CLD = BN + 4;           // fp32 staging row stride
+    constexpr int CLD = BN + 8;           // bf16 staging row stride (elements); rows stay 16-B aligned
     constexpr int STAGE_BYTES = 2 * (A_BYTES + B_BYTES);
-    constexpr int C_BYTES = BM * CLD * 4;
-    constexpr int LDS_BYTES = STAGE_BYTES > C_BYTES ? STAGE_BYTES : C_BYTES;
+    constexpr int C_BYTES = BM * CLD * 2;
+    constexpr int NV = BN / 8;            // 8-channel vectors per tile row
+    constexpr int TR = 256 / NV;          // threads that share one channel vector in the output loop
+    constexpr int RED_BYTES = TR * 2 * BN * 4;
+    constexpr int EPI_BYTES = C_BYTES + RED_BYTES;
+    constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/thread mismatch");
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + 2 * 4 * BN * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
-    // ---- XCD-aware tile id: blocks b, b+8, ... share an XCD; give each XCD a contiguous range.
+    // ---- persistent workgroups: block b processes virtual tile ids b, b + gridDim, ...
+    // XCD-aware remap of the virtual id: ids v, v+8, ... run on one XCD (round-robin dispatch);
+    // give each XCD a contiguous range of tiles so tiles that share activation rows share an L2.
     const int n_tiles_n = (p.N + BN - 1) / BN;
     const int n_tiles_m = (int)((p.M + BM - 1) / BM);
     const int nwg = n_tiles_m * n_tiles_n;
-    int wgid;
-    {
-        int orig = blockIdx.x;
-        int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    }
-    const int tile_n = wgid % n_tiles_n;
-    const int tile_m = wgid / n_tiles_n;
-    const long long m0 = (long long)tile_m * BM;
-    const int n0 = tile_n * BN;
+    const int HgWg = p.Hg * p.Wg;
 
-    // ---- per-thread staging geometry
+    // ---- per-thread staging geometry of the tile whose loads are being issued
     const int chunk = tid % CH;
     const int row_in_pass = tid / CH;
     int a_base[A_IT], a_y[A_IT], a_x[A_IT];
     bool a_ok[A_IT];
-    const int HgWg = p.Hg * p.Wg;
+    unsigned b_off[B_IT];               // byte offset of the weight row, or PDT_OOB_OFFSET
+    long long ld_m0 = 0;
+    int ld_n0 = 0;
+    auto setup_tile = [&](int v) {
+        int xcd = v & 7, q = nwg >> 3, r = nwg & 7;
+        int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        const int tile_n = wgid % n_tiles_n;
+        const int tile_m = wgid / n_tiles_n;
+        ld_m0 = (long long)tile_m * BM;
+        ld_n0 = tile_n * BN;
 #pragma unroll
-    for (int j = 0; j < A_IT; ++j) {
-        long long m = m0 + row_in_pass + j * RPP;
-        a_ok[j] = m < p.M;
-        unsigned mm = a_ok[j] ? (unsigned)m : 0u;          // M < 2^31 (checked by the launcher)
-        int b = (int)(mm / (unsigned)HgWg);
-        int rem = (int)(mm - (unsigned)b * (unsigned)HgWg);
-        int y = (int)((unsigned)rem / (unsigned)p.Wg), x = rem - y * p.Wg;
-        a_base[j] = b * p.Hi * p.Wi;
-        a_y[j] = y * p.IS;
-        a_x[j] = x * p.IS;
-    }
-    long long b_off[B_IT];
-    bool b_ok[B_IT];
+        for (int j = 0; j < A_IT; ++j) {
+            long long m = ld_m0 + row_in_pass + j * RPP;
+            a_ok[j] = m < p.M;
+            unsigned mm = a_ok[j] ? (unsigned)m : 0u;          // M < 2^31 (checked by the launcher)
+            int b = (int)(mm / (unsigned)HgWg);
+            int rem = (int)(mm - (unsigned)b * (unsigned)HgWg);
+            int y = (int)((unsigned)rem / (unsigned)p.Wg), x = rem - y * p.Wg;
+            a_base[j] = b * p.Hi * p.Wi;
+            a_y[j] = y * p.IS;
+            a_x[j] = x * p.IS;
+        }
 #pragma unroll
-    for (int j = 0; j < B_IT; ++j) {
-        int n = n0 + row_in_pass + j * RPP;
-        b_ok[j] = n < p.N;
-        b_off[j] = (long long)(b_ok[j] ? n : 0) * p.wrow + chunk * 8;
-    }
+        for (int j = 0; j < B_IT; ++j) {
+            int n = ld_n0 + row_in_pass + j * RPP;
+            b_off[j] = n < p.N ? (unsigned)(n * p.wrow + chunk * 8) * 2u : PDT_OOB_OFFSET;
+        }
+    };
+    const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t wgt_rsrc = make_rsrc(p.wgt, p.wgt_bytes);
 
-    bf16x8 a_reg[A_IT], b_reg[B_IT];
     const int kc = p.Ci / BK;             // K steps per tap
     const int nk = p.T * kc;
 
-    auto load_tiles = [&](int t, int c0) {
-        const int oy = p.offy[t], ox = p.offx[t];
-        const long long wofs = (long long)p.widx[t] * p.Ci + c0;
+    // Two register sets: the loads of K step k+2 are issued before the MFMAs of step k and are
+    // only written to LDS at the end of step k+1, so they have two compute phases to land.
+    bf16x8 a_r0[A_IT], b_r0[B_IT], a_r1[A_IT], b_r1[B_IT];
+
+    auto load_tiles = [&](bf16x8 (&a_reg)[A_IT], bf16x8 (&b_reg)[B_IT], int ks) {
+        const int t = __builtin_amdgcn_readfirstlane(ks / kc);
+        const int c0 = (ks - t * kc) * BK;
+        int oy, ox, wi;
+        unpack_tap(p.taps[t], oy, ox, wi);
+        const unsigned wofs = (unsigned)(wi * p.Ci + c0) * 2u;
 #pragma unroll
         for (int j = 0; j < A_IT; ++j) {
             int iy = a_y[j] + oy, ix = a_x[j] + ox;
             bool ok = a_ok[j] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            if (ok) {
-                long long off = (long long)(a_base[j] + iy * p.Wi + ix) * p.pix_stride + c0 + chunk * 8;
-                a_reg[j] = ld_bf16x8(p.in + off);
-            } else {
-                a_reg[j] = zero_bf16x8();
-            }
+            unsigned off = (unsigned)((a_base[j] + iy * p.Wi + ix) * p.pix_stride + c0 + chunk * 8) * 2u;
+            a_reg[j] = buf_ld_bf16x8(in_rsrc, ok ? off : PDT_OOB_OFFSET);
         }
 #pragma unroll
-        for (int j = 0; j < B_IT; ++j) {
-            if (b_ok[j]) b_reg[j] = ld_bf16x8(p.wgt + b_off[j] + wofs);
-            else b_reg[j] = zero_bf16x8();
-        }
+        for (int j = 0; j < B_IT; ++j)
+            b_reg[j] = buf_ld_bf16x8(wgt_rsrc, b_off[j] == PDT_OOB_OFFSET ? PDT_OOB_OFFSET : b_off[j] + wofs);
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](const bf16x8 (&a_reg)[A_IT], const bf16x8 (&b_reg)[B_IT], int buf) {
         unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
         unsigned char* Bs = As + A_BYTES;
 #pragma unroll
@@ -162,144 +183,201 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
         }
     };
 
+    // acc[i][j]: operands are swapped (weights feed the MFMA "A" side), so the 16x16 result has
+    // channels on its rows: lane (fq, frow) holds pixel i*16+frow, channels j*16 + fq*4 + {0..3}.
     f32x4 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     const int frow = lane & 15, fq = lane >> 4;
 
+    auto compute = [&](int buf) {
+        const unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
+        const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            bf16x8 af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                int row = wm * WTM + i * 16 + frow;
+                af[i] = *reinterpret_cast<const bf16x8*>(As + row * RB + (swz_chunk<BK>(row, kk * 4 + fq) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                int row = wn * WTN + j * 16 + frow;
+                bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * RB + (swz_chunk<BK>(row, kk * 4 + fq) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    bf16* Cs = reinterpret_cast<bf16*>(smem);
+    float* red = reinterpret_cast<float*>(smem + C_BYTES);     // [TR][2][BN]
+    const bool want_stats = p.stat_acc != nullptr;
+
+    int v = blockIdx.x;                       // the launcher guarantees gridDim.x <= nwg
+    setup_tile(v);
     if (nk > 0) {
-        int t = 0, cstep = 0;
-        load_tiles(0, 0);
-        store_tiles(0);
-        __syncthreads();
-        int cur = 0;
-        for (int ks = 0; ks < nk; ++ks) {
-            int nt = t, ncs = cstep + 1;
-            if (ncs == kc) { ncs = 0; nt = t + 1; }
-            const bool has_next = ks + 1 < nk;
-            if (has_next) load_tiles(nt, ncs * BK);
+        load_tiles(a_r0, b_r0, 0);
+        if (nk > 1) load_tiles(a_r1, b_r1, 1);
+    }
+    while (true) {
+        const long long m0 = ld_m0;           // the tile being computed now
+        const int n0 = ld_n0;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-            const unsigned char* As = smem + cur * (A_BYTES + B_BYTES);
-            const unsigned char* Bs = As + A_BYTES;
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                bf16x8 af[MI], bfr[NI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    int row = wm * WTM + i * 16 + frow;
-                    af[i] = *reinterpret_cast<const bf16x8*>(As + row * RB + (swz_chunk<BK>(row, kk * 4 + fq) << 4));
-                }
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    int row = wn * WTN + j * 16 + frow;
-                    bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * RB + (swz_chunk<BK>(row, kk * 4 + fq) << 4));
-                }
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            }
-            if (has_next) store_tiles(cur ^ 1);
+        if (nk > 0) {
+            store_tiles(a_r0, b_r0, 0);
             __syncthreads();
-            cur ^= 1;
-            t = nt;
-            cstep = ncs;
-        }
-    }
-
-    // ---- epilogue: accumulators -> fp32 LDS image -> (stats) -> fused output ------------------
-    float* Cs = reinterpret_cast<float*>(smem);
-    float* red = reinterpret_cast<float*>(smem + LDS_BYTES);   // [2][4][BN] partials for stats
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int row = wm * WTM + i * 16 + fq * 4 + r;
-                int col = wn * WTN + j * 16 + frow;
-                Cs[row * CLD + col] = acc[i][j][r];
-            }
-    __syncthreads();
-
-    long long rows_left = p.M - m0;
-    const int rows_valid = rows_left < BM ? (int)rows_left : BM;
-
-    if (p.stat_acc) {
-        constexpr int PARTS = 256 / BN;          // threads per column
-        constexpr int PARTS_C = PARTS > 0 ? PARTS : 1;
-        if (BN <= 256) {
-            int col = tid % BN, part = tid / BN;
-            int n = n0 + col;
-            float sh = (p.stat_shift && n < p.N) ? p.stat_shift[n] : 0.0f;
-            float s0 = 0.f, s1 = 0.f;
-            for (int r = part; r < rows_valid; r += PARTS_C) {
-                float d = Cs[r * CLD + col] - sh;
-                s0 += d;
-                s1 += d * d;
-            }
-            red[(0 * 4 + part) * BN + col] = s0;
-            red[(1 * 4 + part) * BN + col] = s1;
-        }
-        __syncthreads();
-        for (int i = tid; i < 2 * BN; i += 256) {
-            int which = i / BN, col = i % BN;
-            int n = n0 + col;
-            if (n < p.N) {
-                float s = 0.f;
-#pragma unroll
-                for (int q = 0; q < PARTS_C; ++q) s += red[(which * 4 + q) * BN + col];
-                atomicAdd(p.stat_acc + ((size_t)(blockIdx.x % NREP) * 2 + which) * p.N + n, s);
+            for (int ks = 0; ks < nk; ks += 2) {
+                // even step: LDS[0] holds step ks, set 1 holds step ks+1, set 0 is free
+                if (ks + 2 < nk) load_tiles(a_r0, b_r0, ks + 2);
+                compute(0);
+                if (ks + 1 < nk) store_tiles(a_r1, b_r1, 1);
+                __syncthreads();
+                if (ks + 1 >= nk) break;
+                // odd step: LDS[1] holds step ks+1, set 0 holds step ks+2, set 1 is free
+                if (ks + 3 < nk) load_tiles(a_r1, b_r1, ks + 3);
+                compute(1);
+                if (ks + 2 < nk) store_tiles(a_r0, b_r0, 0);
+                __syncthreads();
             }
         }
-    }
 
-    constexpr int NV = BN / 8;                   // 8-channel vectors per tile row
-    for (int v = tid; v < BM * NV; v += 256) {
-        int row = v / NV, cv = v % NV;
-        if (row >= rows_valid) continue;
-        int n = n0 + cv * 8;
-        if (n >= p.ldo) continue;                // ldo is padded to a multiple of 8 by the host
-        long long m = m0 + row;
-        long long orow;
-        if (p.simple_out) {
-            orow = m;
-        } else {
-            unsigned mu = (unsigned)m;
-            int b = (int)(mu / (unsigned)HgWg);
-            int rem = (int)(mu - (unsigned)b * (unsigned)HgWg);
-            int y = (int)((unsigned)rem / (unsigned)p.Wg), x = rem - y * p.Wg;
-            orow = ((long long)b * p.Ho + (y * p.OS + p.oy0)) * p.Wo + (x * p.OS + p.ox0);
+        // Cross-tile pipelining: issue the first loads of this block's NEXT tile now, so their
+        // latency is covered by the epilogue below.
+        const int vn = v + gridDim.x;
+        const bool more = vn < nwg;
+        if (more) {
+            setup_tile(vn);
+            if (nk > 0) {
+                load_tiles(a_r0, b_r0, 0);
+                if (nk > 1) load_tiles(a_r1, b_r1, 1);
+            }
         }
-        const float* src = Cs + row * CLD + cv * 8;
-        f32x4 lo = *reinterpret_cast<const f32x4*>(src);
-        f32x4 hi = *reinterpret_cast<const f32x4*>(src + 4);
-        float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+
+        // ---- epilogue -----------------------------------------------------------------------
+        long long rows_left = p.M - m0;
+        const int rows_valid = rows_left < BM ? (int)rows_left : BM;
+
         if (p.bias) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) f[k] += (n + k < p.N) ? p.bias[n + k] : 0.0f;
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int n = n0 + wn * WTN + j * 16 + fq * 4 + r;
+                    float bv = n < p.N ? p.bias[n] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) acc[i][j][r] += bv;
+                }
         }
-        long long o = orow * p.ldo + n;
-        if (p.addend) {
-            bf16x8 a = ld_bf16x8(p.addend + o);
-            if (p.mask) {
-                bf16x8 mk = ld_bf16x8(p.mask + o);
+
+        // accumulators -> bf16 tile image in LDS (8-byte writes: 4 consecutive channels of a pixel)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) f[k] += bf2f(mk[k]) > 0.0f ? bf2f(a[k]) : 0.0f;
-            } else {
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) f[k] += bf2f(a[k]);
+            for (int j = 0; j < NI; ++j) {
+                int row = wm * WTM + i * 16 + frow;
+                int col = wn * WTN + j * 16 + fq * 4;
+                bf16x4 pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk[r] = f2bf(acc[i][j][r]);
+                *reinterpret_cast<bf16x4*>(Cs + row * CLD + col) = pk;
+            }
+        __syncthreads();
+
+        // Output loop: thread t always handles channel vector t % NV, rows t / NV + k*TR.  The BN
+        // statistics of those 8 channels are accumulated on the way (from the bf16-rounded values
+        // that are stored: what a separate statistics pass over the output would see).
+        const int cv = tid % NV;
+        const int n = n0 + cv * 8;
+        float sh[8], s0[8], s1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            sh[k] = (want_stats && p.stat_shift && n + k < p.N) ? p.stat_shift[n + k] : 0.0f;
+            s0[k] = 0.f;
+            s1[k] = 0.f;
+        }
+        if (n < p.ldo) {                         // ldo is a multiple of 8 (checked by the launcher)
+            for (int row = tid / NV; row < rows_valid; row += TR) {
+                long long m = m0 + row;
+                long long orow;
+                if (p.simple_out) {
+                    orow = m;
+                } else {
+                    unsigned mu = (unsigned)m;
+                    int b = (int)(mu / (unsigned)HgWg);
+                    int rem = (int)(mu - (unsigned)b * (unsigned)HgWg);
+                    int y = (int)((unsigned)rem / (unsigned)p.Wg), x = rem - y * p.Wg;
+                    orow = ((long long)b * p.Ho + (y * p.OS + p.oy0)) * p.Wo + (x * p.OS + p.ox0);
+                }
+                bf16x8 ov = *reinterpret_cast<const bf16x8*>(Cs + row * CLD + cv * 8);
+                long long o = orow * p.ldo + n;
+                if (p.addend) {
+                    bf16x8 a = ld_bf16x8(p.addend + o);
+                    if (p.mask) {
+                        bf16x8 mk = ld_bf16x8(p.mask + o);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            ov[k] = f2bf(bf2f(ov[k]) + (bf2f(mk[k]) > 0.0f ? bf2f(a[k]) : 0.0f));
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) ov[k] = f2bf(bf2f(ov[k]) + bf2f(a[k]));
+                    }
+                }
+                st_bf16x8(p.out + o, ov);
+                if (want_stats) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float d = bf2f(ov[k]) - sh[k];
+                        s0[k] += d;
+                        s1[k] += d * d;
+                    }
+                }
             }
         }
-        bf16x8 ov;
+        if (want_stats) {
+            const int tr = tid / NV;
+            float* r0 = red + (tr * 2 + 0) * BN + cv * 8;
+            float* r1 = red + (tr * 2 + 1) * BN + cv * 8;
+            *reinterpret_cast<f32x4*>(r0) = f32x4{s0[0], s0[1], s0[2], s0[3]};
+            *reinterpret_cast<f32x4*>(r0 + 4) = f32x4{s0[4], s0[5], s0[6], s0[7]};
+            *reinterpret_cast<f32x4*>(r1) = f32x4{s1[0], s1[1], s1[2], s1[3]};
+            *reinterpret_cast<f32x4*>(r1 + 4) = f32x4{s1[4], s1[5], s1[6], s1[7]};
+            __syncthreads();
+            for (int i = tid; i < 2 * BN; i += 256) {
+                int which = i / BN, col = i % BN;
+                if (n0 + col < p.N) {
+                    float sum = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) ov[k] = f2bf(f[k]);
-        st_bf16x8(p.out + o, ov);
+                    for (int q = 0; q < TR; ++q) sum += red[(q * 2 + which) * BN + col];
+                    atomicAdd(p.stat_acc + ((size_t)(blockIdx.x % NREP) * 2 + which) * p.N + n0 + col, sum);
+                }
+            }
+        }
+        if (!more) break;
+        v = vn;
+        __syncthreads();          // the epilogue's LDS reads are done before the next tile is staged
     }
+}
+
+// Resident workgroups of one instantiation on the whole chip (queried once, then cached).
+template <int BM, int BN, int BK, int WM, int WN>
+static int resident_blocks() {
+    static int cached = 0;
+    if (cached > 0) return cached;
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 512;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, igemm_kernel<BM, BN, BK, WM, WN>, 256, 0) != hipSuccess ||
+        per_cu <= 0)
+        per_cu = 2;
+    cached = per_cu * cus;
+    return cached;
 }
 
 template <int BM, int BN, int BK, int WM, int WN>
@@ -308,7 +386,9 @@ static int launch_igemm(const IgemmParams& p, hipStream_t s) {
     long long n_tiles_m = (p.M + BM - 1) / BM;
     long long nwg = n_tiles_m * n_tiles_n;
     if (nwg <= 0 || nwg > 0x7fffffffLL) return -2;
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WM, WN>), dim3((unsigned)nwg), dim3(256), 0, s, p);
+    long long grid = resident_blocks<BM, BN, BK, WM, WN>();
+    if (grid > nwg) grid = nwg;
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WM, WN>), dim3((unsigned)grid), dim3(256), 0, s, p);
     return pdt_launch_status();
 }
 
@@ -327,11 +407,19 @@ PDT_API int pdt_conv_igemm(const void* in, const void* wgt, void* out, const voi
     p.addend = (const bf16*)addend; p.mask = (const bf16*)mask; p.bias = bias;
     p.stat_acc = stat_acc; p.stat_shift = stat_shift;
     p.M = M; p.Hi = Hi; p.Wi = Wi; p.pix_stride = pix_stride; p.Ci = Ci;
+    {
+        long long images = M / ((long long)Hg * Wg);
+        long long in_b = images * Hi * Wi * pix_stride * 2, w_b = (long long)N * wrow * 2;
+        if (in_b >= (long long)PDT_OOB_OFFSET || w_b >= (long long)PDT_OOB_OFFSET) return -7;
+        p.in_bytes = (unsigned)in_b;
+        p.wgt_bytes = (unsigned)w_b;
+    }
     p.Hg = Hg; p.Wg = Wg; p.IS = IS; p.Ho = Ho; p.Wo = Wo; p.OS = OS; p.oy0 = oy0; p.ox0 = ox0;
     p.N = N; p.ldo = ldo; p.wrow = wrow; p.T = T;
     p.simple_out = (OS == 1 && oy0 == 0 && ox0 == 0 && Hg == Ho && Wg == Wo) ? 1 : 0;
-    for (int i = 0; i < T; ++i) { p.offy[i] = offy[i]; p.offx[i] = offx[i]; p.widx[i] = widx[i]; }
-    for (int i = T; i < MAX_TAPS; ++i) { p.offy[i] = 0; p.offx[i] = 0; p.widx[i] = 0; }
+    for (int i = 0; i < T; ++i)
+        p.taps[i] = ((int)offy[i] & 0xff) | (((int)offx[i] & 0xff) << 8) | ((int)widx[i] << 16);
+    for (int i = T; i < MAX_TAPS; ++i) p.taps[i] = 0;
     if (T > 0 && Ci % 32 != 0) return -5;
     if (tile == 0) {
         if (T > 0 && Ci % 64 != 0) tile = 4;

@@ -28,15 +28,23 @@ struct WgradParams {
     const bf16* in;
     float* dw;
     long long M;
+    unsigned in_bytes, dy_bytes;       // tensor sizes for the buffer descriptors
     int Hi, Wi, pix_stride, Ci;
     int Hg, Wg, IS;
     int N, ldy, wrow, T;
     int splitk;
     long long rows_per_split;
-    signed char offy[MAX_TAPS];
-    signed char offx[MAX_TAPS];
-    unsigned short widx[MAX_TAPS];
+    // one 32-bit word per tap: offy (int8) | offx (int8) << 8 | widx (uint16) << 16.  Sub-dword
+    // entries would be fetched with VECTOR loads (no scalar byte loads on gfx9), whose waits
+    // drain the tile prefetches; a dword indexed by a wave-uniform tap is one s_load_dword.
+    int taps[MAX_TAPS];
 };
+
+__device__ __forceinline__ void unpack_tap(int w, int& oy, int& ox, int& widx) {
+    oy = (int)(signed char)(w & 0xff);
+    ox = (int)(signed char)((w >> 8) & 0xff);
+    widx = (w >> 16) & 0xffff;
+}
 
 __device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char* base0, const unsigned char* base1) {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -83,7 +91,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     const int tap = in_idx / n_cin;
     const int cin_tile = in_idx % n_cin;
     const int co0 = ct * BMO, ci0 = cin_tile * BNC;
-    const int oy = p.offy[tap], ox = p.offx[tap];
+    int oy, ox, wi_tap;
+    unpack_tap(p.taps[__builtin_amdgcn_readfirstlane(tap)], oy, ox, wi_tap);
 
     const long long r_begin = (long long)split * p.rows_per_split;
     long long r_end = r_begin + p.rows_per_split;
@@ -96,33 +105,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     const bool b_col_ok = ci0 + b_cv * 8 < p.Ci;
     const int HgWg = p.Hg * p.Wg;
 
+    const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(p.dy, p.dy_bytes);
+    const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(p.in, p.in_bytes);
     bf16x8 a_reg[A_IT], b_reg[B_IT];
+    // branch-free staging loads: lanes outside the slice / tile / image read zeros through the
+    // buffer descriptor's range check
     auto load_tiles = [&](long long r0) {
 #pragma unroll
         for (int j = 0; j < A_IT; ++j) {
             int row = a_row + j * A_RPP;
             long long m = r0 + row;
-            if (row < BKP && m < r_end && a_col_ok) a_reg[j] = ld_bf16x8(p.dy + m * p.ldy + co0 + a_cv * 8);
-            else a_reg[j] = zero_bf16x8();
+            bool ok = row < BKP && m < r_end && a_col_ok;
+            unsigned off = (unsigned)((unsigned)m * (unsigned)p.ldy + co0 + a_cv * 8) * 2u;
+            a_reg[j] = buf_ld_bf16x8(dy_rsrc, ok ? off : PDT_OOB_OFFSET);
         }
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) {
             int row = b_row + j * B_RPP;
             long long m = r0 + row;
-            bool ok = row < BKP && m < r_end && b_col_ok;
-            if (ok) {
-                unsigned mu = (unsigned)m;                      // M < 2^31 (checked by the launcher)
-                int b = (int)(mu / (unsigned)HgWg);
-                int rem = (int)(mu - (unsigned)b * (unsigned)HgWg);
-                int y = (int)((unsigned)rem / (unsigned)p.Wg), x = rem - y * p.Wg;
-                int iy = y * p.IS + oy, ix = x * p.IS + ox;
-                ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-                if (ok) {
-                    long long off = ((long long)(b * p.Hi + iy) * p.Wi + ix) * p.pix_stride + ci0 + b_cv * 8;
-                    b_reg[j] = ld_bf16x8(p.in + off);
-                }
-            }
-            if (!ok) b_reg[j] = zero_bf16x8();
+            unsigned mu = m < r_end ? (unsigned)m : 0u;         // M < 2^31 (checked by the launcher)
+            int b = (int)(mu / (unsigned)HgWg);
+            int rem = (int)(mu - (unsigned)b * (unsigned)HgWg);
+            int y = (int)((unsigned)rem / (unsigned)p.Wg), x = rem - y * p.Wg;
+            int iy = y * p.IS + oy, ix = x * p.IS + ox;
+            bool ok = row < BKP && m < r_end && b_col_ok && (unsigned)iy < (unsigned)p.Hi &&
+                      (unsigned)ix < (unsigned)p.Wi;
+            unsigned off = (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.pix_stride + ci0 + b_cv * 8) * 2u;
+            b_reg[j] = buf_ld_bf16x8(in_rsrc, ok ? off : PDT_OOB_OFFSET);
         }
     };
     auto store_tiles = [&](int buf) {
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 
     if (nk == 0) return;
     const int frow = lane & 15, fq = lane >> 4;
-    const long long wofs = (long long)p.widx[tap] * p.Ci;
+    const long long wofs = (long long)wi_tap * p.Ci;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -205,13 +214,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 }
 
 template <int BMO, int BNC, int WM, int WN>
-static int launch_wgrad(WgradParams& p, hipStream_t s, int target_blocks) {
+static int launch_wgrad(WgradParams& p, hipStream_t s, int target_blocks, long long atomic_budget_bytes) {
     int n_ct = (p.N + BMO - 1) / BMO;
     int n_cin = (p.Ci + BNC - 1) / BNC;
     long long tiles = (long long)n_ct * n_cin * p.T;
     long long max_split = (p.M + 2 * BKP - 1) / (2 * BKP);     // at least two K steps per slice
     long long split = (target_blocks + tiles - 1) / tiles;
     if (split > max_split) split = max_split;
+    // Every slice adds the whole fp32 output once with float atomics, which run at ~1.3 TB/s
+    // chip-wide: keep split * output bytes within a budget so the atomics stay a small part of
+    // the kernel (large-output layers have a short reduction anyway).
+    long long out_bytes = (long long)p.N * p.T * p.Ci * 4;
+    long long budget_split = atomic_budget_bytes / (out_bytes > 0 ? out_bytes : 1);
+    if (budget_split < 1) budget_split = 1;
+    if (split > budget_split) split = budget_split;
     if (split < 1) split = 1;
     long long rps = (p.M + split - 1) / split;
     rps = (rps + BKP - 1) / BKP * BKP;
@@ -228,7 +244,7 @@ static int launch_wgrad(WgradParams& p, hipStream_t s, int target_blocks) {
 PDT_API int pdt_conv_wgrad(const void* dy, const void* in, float* dw, long long M, int Hi, int Wi, int pix_stride,
                            int Ci, int Hg, int Wg, int IS, int N, int ldy, int wrow, int T, const signed char* offy,
                            const signed char* offx, const unsigned short* widx, int tile, int target_blocks,
-                           hipStream_t s) {
+                           int atomic_budget_mb, hipStream_t s) {
     if (T <= 0 || T > MAX_TAPS) return -3;
     if (M <= 0) return 0;
     if (M >= 0x7fffffffLL) return -2;
@@ -236,20 +252,29 @@ PDT_API int pdt_conv_wgrad(const void* dy, const void* in, float* dw, long long 
     WgradParams p;
     p.dy = (const bf16*)dy; p.in = (const bf16*)in; p.dw = dw;
     p.M = M; p.Hi = Hi; p.Wi = Wi; p.pix_stride = pix_stride; p.Ci = Ci;
+    {
+        long long images = M / ((long long)Hg * Wg);
+        long long in_b = images * Hi * Wi * pix_stride * 2, dy_b = M * (long long)ldy * 2;
+        if (in_b >= (long long)PDT_OOB_OFFSET || dy_b >= (long long)PDT_OOB_OFFSET) return -7;
+        p.in_bytes = (unsigned)in_b;
+        p.dy_bytes = (unsigned)dy_b;
+    }
     p.Hg = Hg; p.Wg = Wg; p.IS = IS; p.N = N; p.ldy = ldy; p.wrow = wrow; p.T = T;
-    for (int i = 0; i < T; ++i) { p.offy[i] = offy[i]; p.offx[i] = offx[i]; p.widx[i] = widx[i]; }
-    for (int i = T; i < MAX_TAPS; ++i) { p.offy[i] = 0; p.offx[i] = 0; p.widx[i] = 0; }
+    for (int i = 0; i < T; ++i)
+        p.taps[i] = ((int)offy[i] & 0xff) | (((int)offx[i] & 0xff) << 8) | ((int)widx[i] << 16);
+    for (int i = T; i < MAX_TAPS; ++i) p.taps[i] = 0;
     if (target_blocks <= 0) target_blocks = 2048;
+    long long budget = (long long)(atomic_budget_mb > 0 ? atomic_budget_mb : 24) << 20;
     if (tile == 0) {
         if (Ci <= 32) tile = 3;
         else if (N <= 64 || Ci <= 64) tile = 2;
         else tile = 1;
     }
     switch (tile) {
-        case 1: return launch_wgrad<128, 128, 2, 2>(p, s, target_blocks);
-        case 2: return launch_wgrad<64, 64, 2, 2>(p, s, target_blocks);
-        case 3: return launch_wgrad<64, 32, 2, 2>(p, s, target_blocks);
-        case 4: return launch_wgrad<128, 64, 2, 2>(p, s, target_blocks);
+        case 1: return launch_wgrad<128, 128, 2, 2>(p, s, target_blocks, budget);
+        case 2: return launch_wgrad<64, 64, 2, 2>(p, s, target_blocks, budget);
+        case 3: return launch_wgrad<64, 32, 2, 2>(p, s, target_blocks, budget);
+        case 4: return launch_wgrad<128, 64, 2, 2>(p, s, target_blocks, budget);
         default: return -6;
     }
 }

@@ -60,7 +60,7 @@ _sig("pdt_ce_metrics", _vp, _vp, _vp, _i, _i, _i, _vp)
 _sig("pdt_colsum_add", _vp, _vp, _i, _i, _i, _vp)
 _sig("pdt_conv_igemm", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
      _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp)
-_sig("pdt_conv_wgrad", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp)
+_sig("pdt_conv_wgrad", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp)
 
 
 class HipKernelError(RuntimeError):
@@ -167,9 +167,9 @@ def _igemm(inp, wgt, out, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0
 
 
 def _wgrad(dy, inp, dw, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow, taps: _Taps, tile: int = 0,
-           target_blocks: int = 0) -> None:
+           target_blocks: int = 0, atomic_budget_mb: int = 0) -> None:
     rc = _lib.pdt_conv_wgrad(_p(dy), _p(inp), _p(dw), M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow, taps.T,
-                             taps.offy, taps.offx, taps.widx, tile, target_blocks, _stream())
+                             taps.offy, taps.offx, taps.widx, tile, target_blocks, atomic_budget_mb, _stream())
     _check(rc, "pdt_conv_wgrad")
 
 
@@ -297,14 +297,14 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
 
 
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, R: int, S: int, stride: int, pad: int, dw: torch.Tensor,
-               tile: int = 0, target_blocks: int = 0) -> None:
+               tile: int = 0, target_blocks: int = 0, atomic_budget_mb: int = 0) -> None:
     x = _bf16c(x, "conv_wgrad x")
     dy = _bf16c(dy, "conv_wgrad dy")
     _f32c(dw, "conv_wgrad dw")
     B, Hi, Wi, Ci = x.shape
     _, Ho, Wo, Co = dy.shape
     _wgrad(dy, x, dw, B * Ho * Wo, Hi, Wi, Ci, Ci, Ho, Wo, stride, Co, Co, R * S * Ci, _fprop_taps(R, S, pad),
-           tile=tile, target_blocks=target_blocks)
+           tile=tile, target_blocks=target_blocks, atomic_budget_mb=atomic_budget_mb)
 
 
 def transpose_weights(w: torch.Tensor, wt: torch.Tensor) -> None:

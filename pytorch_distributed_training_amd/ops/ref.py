@@ -90,7 +90,9 @@ def stem_wgrad(x0: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) -> None:
 def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pad: int,
                stat_shift: Optional[torch.Tensor] = None, **_) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """``y = conv(x, w)``; when ``stat_shift`` is given also the shifted per-channel moments of
-    the fp32 result (see :func:`channel_moments`)."""
+    the result (see :func:`channel_moments`).  Here they are taken from the fp32 result; a
+    backend may take them from the rounded ``y`` it stores instead (the HIP kernel does: that is
+    what a separate statistics pass over the output tensor would see)."""
     y32 = F.conv2d(_nchw(x.float()), _w_oihw(w.float()), None, stride, pad)
     y32 = _nhwc(y32)
     stats = channel_moments(y32, stat_shift) if stat_shift is not None else None

@@ -44,7 +44,9 @@ def test_conv_fprop_dgrad_wgrad(hip, device, shape, B):
     y, mom = hip.conv_fprop(x, w, k, k, stride, pad, shift)
     y_ref, mom_ref = ref.conv_fprop(x, w, k, k, stride, pad, shift)
     assert rel_err(y, y_ref) < 1.5e-2
-    assert torch.allclose(mom, mom_ref, rtol=2e-3, atol=2e-3)
+    # the fused statistics are those of the bf16 values actually stored
+    assert torch.allclose(mom, ref.bn_stats(y, shift), rtol=1e-3, atol=1e-3)
+    assert torch.allclose(mom, mom_ref, rtol=1e-2, atol=1e-2)
 
     dy = rnd(*y.shape, device=device)
     wt = torch.empty(Ci, k, k, Co, dtype=torch.bfloat16, device=device)
@@ -119,7 +121,8 @@ def test_stem(hip, device, fmt, B, H):
     y, mom = hip.stem_fprop(x0, wp, shift)
     y_ref, mom_ref = ref.stem_fprop(x0_ref, w, shift)
     assert rel_err(y, y_ref) < 1.5e-2
-    assert torch.allclose(mom, mom_ref, rtol=2e-3, atol=2e-3)
+    assert torch.allclose(mom, ref.bn_stats(y, shift), rtol=1e-3, atol=1e-3)
+    assert torch.allclose(mom, mom_ref, rtol=1e-2, atol=1e-2)
     dy = rnd(*y.shape, device=device)
     dw = torch.zeros(64, 7, 7, 3, dtype=torch.float32, device=device)
     dw_ref = torch.zeros_like(dw)
