@@ -13,8 +13,10 @@ is written out here as a static program for one GPU per process:
   scale/shift(+residual)(+ReLU)``;
 * backward is hand-derived: ``fused ReLU-mask + BN reduce -> [SyncBN: ONE all-reduce of
   2C floats] -> fused BN elementwise -> weight-gradient (accumulates into the flat
-  gradient buffer) -> data-gradient (residual add fused into its epilogue)``.  No
-  autograd graph is recorded;
+  gradient buffer) -> data-gradient``.  The data-gradient epilogue of a block's first conv
+  also adds the other residual path and applies the ReLU backward of the block INPUT, so
+  the gradient that reaches the previous block is already masked and its (largest)
+  BatchNorm backward passes read no mask tensor.  No autograd graph is recorded;
 * after each layer's gradients are final the bucketed reducer
   (:mod:`..parallel.reducer`) is told how far the flat gradient buffer is complete, so
   RCCL all-reduces overlap the rest of backward on a side stream.
@@ -267,8 +269,6 @@ class NativeResNet:
                 out = self._unit_forward(u, out, None, True, train)
             else:
                 out = self._unit_forward(u, out, identity, True, train)
-        if train:
-            self._saved[b.name] = out
         return out
 
     def forward(self, img: torch.Tensor, train: Optional[bool] = None) -> torch.Tensor:
@@ -300,6 +300,7 @@ class NativeResNet:
             pooled = ops.avgpool_fwd(x)
             if train:
                 self._saved["final_hw"] = (x.shape[1], x.shape[2])
+                self._saved["final_out"] = x
                 self._saved["pooled"] = pooled
             P = self.params
             logits = ops.linear_fwd(pooled, P.compute("fc.weight"), P.param("fc.bias"))
@@ -307,9 +308,10 @@ class NativeResNet:
 
     # ------------------------------------------------------------------ backward
     def _block_backward(self, b: BlockSpec, g: torch.Tensor) -> torch.Tensor:
-        """``g``: gradient w.r.t. the block output (after its ReLU).  Returns d(block input)."""
+        """``g``: gradient w.r.t. the block's pre-ReLU sum, i.e. ALREADY multiplied by the mask of
+        the block's output ReLU (the producer of ``g`` fuses that).  Returns the gradient w.r.t.
+        the block input, likewise already masked by the input tensor's own ReLU."""
         P, ops, red = self.params, self.ops, self.reducer
-        out = self._saved.pop(b.name)
         last = len(b.units) - 1
         x_block = self._ctx[b.units[0].bn].x_in
         cur = g
@@ -318,7 +320,7 @@ class NativeResNet:
             u = b.units[i]
             ctx = self._ctx.pop(u.bn)
             if i == last:
-                dy = self._bn_backward(u, ctx, cur, out, MASK_TENSOR)
+                dy = self._bn_backward(u, ctx, cur, None, MASK_NONE)
             else:
                 dy = self._bn_backward(u, ctx, cur, None, MASK_RECOMPUTE)
             key = f"{u.conv}.weight"
@@ -334,18 +336,18 @@ class NativeResNet:
         if b.downsample is not None:
             d = b.downsample
             ctx = self._ctx.pop(d.bn)
-            dyd = self._bn_backward(d, ctx, g, out, MASK_TENSOR)
+            dyd = self._bn_backward(d, ctx, g, None, MASK_NONE)
             keyd = f"{d.conv}.weight"
             ops.conv_wgrad(x_block, dyd, d.ksize, d.ksize, d.stride, d.pad, P.grad(keyd))
             red.mark_ready(P.end_offset(keyd))
-            dx_ds = ops.conv_dgrad(dyd, P.compute(keyd), self._wt_view(keyd), tuple(x_block.shape),
+            other = ops.conv_dgrad(dyd, P.compute(keyd), self._wt_view(keyd), tuple(x_block.shape),
                                    d.ksize, d.ksize, d.stride, d.pad)
-            dx = ops.conv_dgrad(dy_first, P.compute(key0), self._wt_view(key0), tuple(x_block.shape),
-                                u0.ksize, u0.ksize, u0.stride, u0.pad, addend=dx_ds)
         else:
-            dx = ops.conv_dgrad(dy_first, P.compute(key0), self._wt_view(key0), tuple(x_block.shape),
-                                u0.ksize, u0.ksize, u0.stride, u0.pad, addend=g, mask_src=out)
-        return dx
+            other = g                       # identity path
+        # x_block is a post-ReLU tensor (previous block output, or the max-pooled stem activation,
+        # where a zero means the whole pooling window was zero): apply its ReLU backward here.
+        return ops.conv_dgrad(dy_first, P.compute(key0), self._wt_view(key0), tuple(x_block.shape),
+                              u0.ksize, u0.ksize, u0.stride, u0.pad, addend=other, relu_mask=x_block)
 
     def backward(self, dlogits: torch.Tensor) -> None:
         """Back-propagate ``dlogits``; gradients accumulate into the flat gradient buffer."""
@@ -357,7 +359,7 @@ class NativeResNet:
                                      P.grad("fc.weight"), P.grad("fc.bias"))
             red.mark_ready(P.end_offset("fc.bias"))
             H, W = self._saved.pop("final_hw")
-            g = ops.avgpool_bwd(dpooled, H, W)
+            g = ops.avgpool_bwd(dpooled, H, W, relu_mask=self._saved.pop("final_out"))
             for b in reversed(self.spec.blocks):
                 g = self._block_backward(b, g)
             stem = self.spec.stem

@@ -28,7 +28,9 @@
 // registers are four CONSECUTIVE CHANNELS of one pixel.  Epilogue:
 //   * optional per-channel bias (in registers),
 //   * the tile goes to LDS as bf16 with 8-byte writes and leaves as full 16-byte vectors,
-//   * optional "out += addend [* (mask > 0)]"  (residual-gradient accumulation of a block),
+//   * optional "out = (out + addend) * (mask > 0)": residual-gradient accumulation of a block
+//     and the ReLU backward of the tensor the gradient belongs to, so downstream BatchNorm
+//     backward passes need no mask tensor,
 //   * optional BatchNorm statistics: in the output loop every thread keeps meeting the same 8
 //     channels, so per-channel sum(v - s) and sum((v - s)^2) over the tile's valid rows are
 //     accumulated for free on the values being stored, reduced across threads through LDS and
@@ -319,15 +321,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
                 long long o = orow * p.ldo + n;
                 if (p.addend) {
                     bf16x8 a = ld_bf16x8(p.addend + o);
-                    if (p.mask) {
-                        bf16x8 mk = ld_bf16x8(p.mask + o);
 #pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            ov[k] = f2bf(bf2f(ov[k]) + (bf2f(mk[k]) > 0.0f ? bf2f(a[k]) : 0.0f));
-                    } else {
+                    for (int k = 0; k < 8; ++k) ov[k] = f2bf(bf2f(ov[k]) + bf2f(a[k]));
+                }
+                if (p.mask) {
+                    bf16x8 mk = ld_bf16x8(p.mask + o);
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) ov[k] = f2bf(bf2f(ov[k]) + bf2f(a[k]));
-                    }
+                    for (int k = 0; k < 8; ++k) ov[k] = bf2f(mk[k]) > 0.0f ? ov[k] : f2bf(0.0f);
                 }
                 st_bf16x8(p.out + o, ov);
                 if (want_stats) {

@@ -347,8 +347,9 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const bf16* __restrict
     st_bf16x8(out + i * 8, o);
 }
 
-__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf16* __restrict__ dp, bf16* __restrict__ dx, int B,
-                                                           int HW, int C) {
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf16* __restrict__ dp,
+                                                           const bf16* __restrict__ relu_mask,
+                                                           bf16* __restrict__ dx, int B, int HW, int C) {
     int cvec = C / 8;
     long long total = (long long)B * HW * cvec;
     long long stride = (long long)gridDim.x * blockDim.x;
@@ -360,6 +361,11 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf16* __restrict
         bf16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = f2bf(bf2f(v[k]) * inv);
+        if (relu_mask) {
+            bf16x8 mk = ld_bf16x8(relu_mask + i * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = bf2f(mk[k]) > 0.0f ? o[k] : f2bf(0.0f);
+        }
         st_bf16x8(dx + i * 8, o);
     }
 }
@@ -371,10 +377,11 @@ PDT_API int pdt_avgpool_fwd(const void* x, void* out, int B, int HW, int C, hipS
     return pdt_launch_status();
 }
 
-PDT_API int pdt_avgpool_bwd(const void* dp, void* dx, int B, int HW, int C, hipStream_t s) {
+PDT_API int pdt_avgpool_bwd(const void* dp, const void* relu_mask, void* dx, int B, int HW, int C, hipStream_t s) {
     if (C % 8) return -1;
     long long total = (long long)B * HW * (C / 8);
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_grid(total, 1)), dim3(256), 0, s, (const bf16*)dp, (bf16*)dx, B, HW, C);
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_grid(total, 1)), dim3(256), 0, s, (const bf16*)dp,
+                       (const bf16*)relu_mask, (bf16*)dx, B, HW, C);
     return pdt_launch_status();
 }
 

@@ -45,7 +45,7 @@ _sig("pdt_input_pad", _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, 
 _sig("pdt_maxpool_fwd", _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
 _sig("pdt_maxpool_bwd", _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
 _sig("pdt_avgpool_fwd", _vp, _vp, _i, _i, _i, _vp)
-_sig("pdt_avgpool_bwd", _vp, _vp, _i, _i, _i, _vp)
+_sig("pdt_avgpool_bwd", _vp, _vp, _vp, _i, _i, _i, _vp)
 _sig("pdt_transpose_w", _vp, _vp, _i, _i, _i, _i, _vp)
 _sig("pdt_stem_pack", _vp, _vp, _i, _vp)
 _sig("pdt_stem_unpack_add", _vp, _vp, _i, _vp)
@@ -270,7 +270,7 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pa
 
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R: int, S: int, stride: int, pad: int,
-               addend: Optional[torch.Tensor] = None, mask_src: Optional[torch.Tensor] = None, tile: int = 0):
+               addend: Optional[torch.Tensor] = None, relu_mask: Optional[torch.Tensor] = None, tile: int = 0):
     dy = _bf16c(dy, "conv_dgrad dy")
     if wt is None:
         raise ValueError("conv_dgrad: the hip backend needs the transposed weight copy wt[Cin,R,S,Cout]")
@@ -279,8 +279,9 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
     dx = torch.empty(B, Hi, Wi, Ci, dtype=torch.bfloat16, device=dy.device)
     if addend is not None:
         addend = _bf16c(addend, "conv_dgrad addend")
-    if mask_src is not None:
-        mask_src = _bf16c(mask_src, "conv_dgrad mask")
+    mask_src = None
+    if relu_mask is not None:
+        mask_src = _bf16c(relu_mask, "conv_dgrad relu_mask")
     if stride == 1:
         _igemm(dy, wt, dx, B * Hi * Wi, Ho, Wo, Co, Co, Hi, Wi, 1, Hi, Wi, 1, 0, 0, Ci, Ci, R * S * Co,
                _dgrad_taps(R, S, pad, 1, 0, 0), addend=addend, mask=mask_src, tile=tile)
@@ -410,11 +411,13 @@ def avgpool_fwd(x):
     return out
 
 
-def avgpool_bwd(dp, H: int, W: int):
+def avgpool_bwd(dp, H: int, W: int, relu_mask=None):
     dp = _bf16c(dp, "avgpool_bwd")
     B, C = dp.shape
     dx = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=dp.device)
-    _check(_lib.pdt_avgpool_bwd(_p(dp), _p(dx), B, H * W, C, _stream()), "pdt_avgpool_bwd")
+    if relu_mask is not None:
+        relu_mask = _bf16c(relu_mask, "avgpool_bwd relu_mask")
+    _check(_lib.pdt_avgpool_bwd(_p(dp), _p(relu_mask), _p(dx), B, H * W, C, _stream()), "pdt_avgpool_bwd")
     return dx
 
 

@@ -101,17 +101,22 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pa
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: Optional[torch.Tensor], in_shape, R: int, S: int,
                stride: int, pad: int, addend: Optional[torch.Tensor] = None,
-               mask_src: Optional[torch.Tensor] = None, **_) -> torch.Tensor:
-    """``dx = conv_transpose(dy, w) [+ addend * (mask_src > 0)]`` ; ``in_shape = (B, Hi, Wi, Ci)``."""
+               relu_mask: Optional[torch.Tensor] = None, **_) -> torch.Tensor:
+    """``dx = (conv_transpose(dy, w) [+ addend]) [* (relu_mask > 0)]`` ; ``in_shape = (B, Hi, Wi, Ci)``.
+
+    ``addend`` accumulates the other gradient path of a residual block; ``relu_mask`` (the
+    post-ReLU tensor this gradient belongs to) applies that ReLU's backward right here, so the
+    consumers of ``dx`` -- the BatchNorm backward passes of the previous block -- need no mask.
+    The sum is rounded to the activation dtype before the mask, like a separate add would."""
     B, Hi, Wi, Ci = in_shape
     dx = torch.nn.grad.conv2d_input((B, Ci, Hi, Wi), _w_oihw(w.float()), _nchw(dy.float()), stride, pad)
     dx = _nhwc(dx)
+    dx = dx.to(dy.dtype)
     if addend is not None:
-        a = addend.float()
-        if mask_src is not None:
-            a = a * (mask_src.float() > 0)
-        dx = dx + a
-    return dx.to(dy.dtype)
+        dx = (dx.float() + addend.float()).to(dy.dtype)
+    if relu_mask is not None:
+        dx = dx * (relu_mask > 0)
+    return dx
 
 
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, R: int, S: int, stride: int, pad: int, dw: torch.Tensor,
@@ -234,9 +239,12 @@ def avgpool_fwd(x: torch.Tensor) -> torch.Tensor:
     return x.float().mean(dim=(1, 2)).to(x.dtype)
 
 
-def avgpool_bwd(dp: torch.Tensor, H: int, W: int) -> torch.Tensor:
+def avgpool_bwd(dp: torch.Tensor, H: int, W: int, relu_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     B, C = dp.shape
-    return (dp.float() / (H * W)).view(B, 1, 1, C).expand(B, H, W, C).contiguous().to(dp.dtype)
+    dx = (dp.float() / (H * W)).view(B, 1, 1, C).expand(B, H, W, C).contiguous().to(dp.dtype)
+    if relu_mask is not None:
+        dx = dx * (relu_mask > 0)
+    return dx
 
 
 # ---------------------------------------------------------------------------- classifier + loss

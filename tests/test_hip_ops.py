@@ -54,7 +54,7 @@ def test_conv_fprop_dgrad_wgrad(hip, device, shape, B):
     assert torch.equal(wt, w.permute(3, 1, 2, 0).contiguous())
     addend = rnd(*x.shape, device=device)
     mask = rnd(*x.shape, device=device)
-    for a, m in ((None, None), (addend, None), (addend, mask)):
+    for a, m in ((None, None), (addend, None), (addend, mask), (None, mask)):
         dx = hip.conv_dgrad(dy, w, wt, tuple(x.shape), k, k, stride, pad, a, m)
         dx_ref = ref.conv_dgrad(dy, w, None, tuple(x.shape), k, k, stride, pad, a, m)
         assert rel_err(dx, dx_ref) < 1.5e-2
@@ -188,6 +188,8 @@ def test_pooling(hip, device, B, H, C):
     assert rel_err(p, ref.avgpool_fwd(x)) < 1e-2
     dp = rnd(B, C, device=device)
     assert rel_err(hip.avgpool_bwd(dp, H, H), ref.avgpool_bwd(dp, H, H)) < 1e-2
+    mk = rnd(B, H, H, C, device=device)
+    assert rel_err(hip.avgpool_bwd(dp, H, H, mk), ref.avgpool_bwd(dp, H, H, mk)) < 1e-2
 
 
 @pytest.mark.parametrize("B,K,N", [(64, 2048, 1000), (7, 512, 10)])
