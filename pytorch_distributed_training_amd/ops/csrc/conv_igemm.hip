@@ -218,6 +218,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     float* red = reinterpret_cast<float*>(smem + C_BYTES);     // [TR][2][BN]
     const bool want_stats = p.stat_acc != nullptr;
 
+    // BatchNorm partial sums of the output loop's 8 channels (thread t: channel vector t % NV)
+    const int cv = tid % NV;
+    float sh[8], s0[8], s1[8];
+    int stat_n0 = -1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sh[k] = 0.f;
+        s0[k] = 0.f;
+        s1[k] = 0.f;
+    }
+
     int v = blockIdx.x;                       // the launcher guarantees gridDim.x <= nwg
     setup_tile(v);
     if (nk > 0) {
@@ -295,14 +306,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
         // Output loop: thread t always handles channel vector t % NV, rows t / NV + k*TR.  The BN
         // statistics of those 8 channels are accumulated on the way (from the bf16-rounded values
         // that are stored: what a separate statistics pass over the output would see).
-        const int cv = tid % NV;
         const int n = n0 + cv * 8;
-        float sh[8], s0[8], s1[8];
+        if (want_stats && stat_n0 != n0) {       // accumulators are empty whenever n0 changes
+            stat_n0 = n0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            sh[k] = (want_stats && p.stat_shift && n + k < p.N) ? p.stat_shift[n + k] : 0.0f;
-            s0[k] = 0.f;
-            s1[k] = 0.f;
+            for (int k = 0; k < 8; ++k) sh[k] = (p.stat_shift && n + k < p.N) ? p.stat_shift[n + k] : 0.0f;
         }
         if (n < p.ldo) {                         // ldo is a multiple of 8 (checked by the launcher)
             for (int row = tid / NV; row < rows_valid; row += TR) {
@@ -340,7 +348,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
                 }
             }
         }
-        if (want_stats) {
+        // The partial sums stay in registers while this block's next tile covers the same
+        // channels (the usual case: the tile stride of a block is a multiple of the channel-tile
+        // count), so the LDS reduction and the atomics run once per block, not once per tile.
+        if (want_stats && (!more || ld_n0 != n0)) {
             const int tr = tid / NV;
             float* r0 = red + (tr * 2 + 0) * BN + cv * 8;
             float* r1 = red + (tr * 2 + 1) * BN + cv * 8;
@@ -357,6 +368,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
                     for (int q = 0; q < TR; ++q) sum += red[(q * 2 + which) * BN + col];
                     atomicAdd(p.stat_acc + ((size_t)(blockIdx.x % NREP) * 2 + which) * p.N + n0 + col, sum);
                 }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                s0[k] = 0.f;
+                s1[k] = 0.f;
             }
         }
         if (!more) break;
