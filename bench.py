@@ -123,6 +123,7 @@ def main() -> int:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    enqueue = time.perf_counter() - t0          # host time to submit the steps (GPU still running)
     if info.distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -158,6 +159,7 @@ def main() -> int:
                 "grad_buckets_reduced_per_step": (
                     engine.model.reducer.stats["launched"] // max(args.steps + args.warmup, 1)
                     if args.engine == "native" else None),
+                "host_submit_ms_per_step": round(1e3 * enqueue / args.steps, 3),
                 "sync_bn_active": bool(engine.model.sync_bn) if args.engine == "native" else None,
             },
         }), flush=True)

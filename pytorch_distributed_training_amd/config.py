@@ -68,6 +68,7 @@ _SCHEMA: Dict[str, Any] = {
         "checkpoint_dir": (str, None),
         "resume": (str, None),
         "no_wd_bn": (bool, False),
+        "syncbn_overlap": (bool, False),       # async BN-backward all-reduce overlapped with the previous wgrad
         "engine": (str, "native"),             # native | torch
         "max_val_batches": (int, None),
     },
@@ -83,6 +84,7 @@ _SCHEMA: Dict[str, Any] = {
         "debug_sync_check": (int, 0),          # every N iters compare param hashes across ranks
         "collective_timeout_s": (int, 1800),
         "deterministic": (bool, False),
+        "hip_graphs": (bool, True),            # native engine on GPU: capture the step into HIP graphs
     },
 }
 

@@ -48,6 +48,8 @@ class NativeEngine:
             spec, self.device, self.ops, dtype, sync_bn=bool(tr.get("sync_bn", False)), group=group,
             bucket_cap_mb=tr.get("bucket_cap_mb", 25.0), first_bucket_mb=tr.get("first_bucket_mb", 1.0),
             overlap_comm=tr.get("overlap_comm", True),
+            hip_graphs=cfg.get("runtime", {}).get("hip_graphs", True),
+            syncbn_overlap=tr.get("syncbn_overlap", False),
         )
         # Same-seed initialisation on every rank (upstream seeds every worker identically,
         # train_distributed.py:141-142); the eager module is only the initialiser here.

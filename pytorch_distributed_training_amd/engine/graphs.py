@@ -1,0 +1,77 @@
+"""HIP-graph capture of a training step as a *segmented program*.
+
+The native engine's step is a fixed sequence of kernel launches for a given batch shape, so
+its host cost (hundreds of Python -> ctypes -> hipLaunchKernel round trips) can be paid once:
+the step is captured into HIP graphs and replayed.  Collectives stay outside the graphs --
+RCCL calls are issued from the host between graph launches -- so a step becomes
+
+    graph 0, host action 0, graph 1, host action 1, ..., graph n
+
+where a host action is a closure over static tensors (a SyncBN all-reduce, the launch of a
+gradient bucket on the communication stream, the final wait).  With one rank the whole
+forward+backward is a single graph.
+
+Memory: every graph of a program allocates from one private pool; they are replayed in
+capture order and never concurrently, which is the condition under which sharing is safe.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import torch
+
+
+class StepProgram:
+    def __init__(self, device: torch.device) -> None:
+        self.device = device
+        self.items: List[Tuple[str, object]] = []
+        self.pool = torch.cuda.graph_pool_handle()
+        self._cur: Optional[torch.cuda.CUDAGraph] = None
+
+    # ------------------------------------------------------------------ capture side
+    def begin(self) -> None:
+        g = torch.cuda.CUDAGraph()
+        # thread-local error mode: the process group's watchdog thread polls events while we
+        # capture, which the default (global) mode would treat as a capture violation
+        g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+        self._cur = g
+
+    def _end(self) -> None:
+        if self._cur is not None:
+            self._cur.capture_end()
+            self.items.append(("graph", self._cur))
+            self._cur = None
+
+    def host(self, fn: Callable[[], None]) -> None:
+        """Close the current graph, run ``fn`` now (un-captured) and record it, open the next."""
+        self._end()
+        fn()
+        self.items.append(("host", fn))
+        self.begin()
+
+    def abort(self) -> None:
+        if self._cur is not None:
+            try:
+                self._cur.capture_end()
+            except Exception:       # noqa: BLE001 -- the capture is already invalid
+                pass
+            self._cur = None
+
+    def finish(self) -> None:
+        self._end()
+
+    # ------------------------------------------------------------------ replay side
+    def replay(self) -> None:
+        for kind, item in self.items:
+            if kind == "graph":
+                item.replay()
+            else:
+                item()
+
+    @property
+    def num_graphs(self) -> int:
+        return sum(1 for k, _ in self.items if k == "graph")
+
+    @property
+    def num_host_actions(self) -> int:
+        return sum(1 for k, _ in self.items if k == "host")

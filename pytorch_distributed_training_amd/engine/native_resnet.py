@@ -74,7 +74,8 @@ class _UnitCtx:
 class NativeResNet:
     def __init__(self, spec: ResNetSpec, device: torch.device, ops, compute_dtype: torch.dtype = torch.bfloat16,
                  sync_bn: bool = False, group=None, bucket_cap_mb: float = 25.0, first_bucket_mb: float = 1.0,
-                 overlap_comm: bool = True, bn_momentum: float = 0.1, bn_eps: float = 1e-5) -> None:
+                 overlap_comm: bool = True, bn_momentum: float = 0.1, bn_eps: float = 1e-5,
+                 hip_graphs: bool = False, syncbn_overlap: bool = False) -> None:
         self.spec = spec
         self.device = torch.device(device)
         self.ops = ops
@@ -84,6 +85,7 @@ class NativeResNet:
         self.world = dist.get_world_size(group) if initialized else 1
         forced = initialized and os.environ.get("PDT_FORCE_COLLECTIVES") == "1"   # debug: see GradReducer
         self.sync_bn = bool(sync_bn) and (self.world > 1 or forced)
+        self.syncbn_overlap = bool(syncbn_overlap)
         self.bn_momentum = bn_momentum
         self.bn_eps = bn_eps
         self.training = True
@@ -119,6 +121,14 @@ class NativeResNet:
         self._eval_affine: Optional[Dict[str, Tuple[torch.Tensor, torch.Tensor]]] = None
         self._ctx: Dict[str, _UnitCtx] = {}
         self._saved: Dict[str, object] = {}
+        self._deferred = None            # weight-gradient closure held back under SyncBN (see _wgrad)
+        # Step graphs (see .graphs): one captured program per batch signature.
+        env = os.environ.get("PDT_HIP_GRAPHS")       # 0 = off, 1 = on, force = on whatever the segment count
+        self.hip_graphs = (bool(hip_graphs) if env is None else env in ("1", "force")) and self.device.type == "cuda"
+        self._force_graphs = env == "force"
+        self._rec = None                 # StepProgram being captured, else None
+        self._plans: Dict[tuple, object] = {}
+        self._eager_seen: Dict[tuple, int] = {}
         self.refresh_derived_weights()
 
     # ------------------------------------------------------------------ parameters / state
@@ -145,9 +155,10 @@ class NativeResNet:
             for u in self.units[1:]:
                 key = f"{u.conv}.weight"
                 ops.transpose_weights(P.compute(key), self._wt_view(key))
-        self._stem_w = ops.prepare_stem_weight(P.compute("conv1.weight"))
+        # refreshed in place: captured step graphs hold these addresses
+        self._stem_w = ops.prepare_stem_weight(P.compute("conv1.weight"), out=self._stem_w)
         prep_fc = getattr(ops, "prepare_fc", None)
-        self._fc_aux = prep_fc(P.compute("fc.weight")) if prep_fc is not None else None
+        self._fc_aux = prep_fc(P.compute("fc.weight"), out=self._fc_aux) if prep_fc is not None else None
         self._eval_affine = None
 
     def train(self, mode: bool = True) -> "NativeResNet":
@@ -210,10 +221,20 @@ class NativeResNet:
             self._eval_affine = None
 
     # ------------------------------------------------------------------ BN helpers
+    def _host(self, fn) -> None:
+        """A host-side action of the step (collective, stream/event call): run it now; while a
+        step program is being captured it also ends the current graph and is recorded, so the
+        replay issues it at the same point between two graphs."""
+        if self._rec is None:
+            fn()
+        else:
+            self._rec.host(fn)
+
     def _bn_train(self, u: ConvBNSpec, ctx: _UnitCtx, moments: torch.Tensor, n_local: int) -> None:
         P = self.params
         if self.sync_bn:
-            dist.all_reduce(moments, group=self.group)
+            group = self.group
+            self._host(lambda: dist.all_reduce(moments, group=group))
             inv_world, count = 1.0 / self.world, n_local * self.world
         else:
             inv_world, count = 1.0, n_local
@@ -221,7 +242,6 @@ class NativeResNet:
             moments, inv_world, P.param(f"{u.bn}.weight"), P.param(f"{u.bn}.bias"),
             self.rm(u.bn), self.rv(u.bn), self.bn_momentum, self.bn_eps, count)
         ctx.count = count
-        self.num_batches_tracked[u.bn] += 1
 
     def _bn_backward(self, u: ConvBNSpec, ctx: _UnitCtx, g: torch.Tensor, mask_src, mask_mode: int) -> torch.Tensor:
         """Gradient w.r.t. the raw conv output; accumulates dgamma / dbeta into the flat buffer."""
@@ -229,9 +249,36 @@ class NativeResNet:
         sums = ops.bn_bwd_reduce(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, mask_src, mask_mode,
                                  P.grad(f"{u.bn}.weight"), P.grad(f"{u.bn}.bias"))
         if self.sync_bn:
-            dist.all_reduce(sums, group=self.group)
+            # The all-reduce sits on the critical path (dgrad needs its result).  With
+            # ``syncbn_overlap`` the weight gradient of the unit processed just before, which is
+            # independent of it, is enqueued between the start and the wait of an asynchronous
+            # collective.  That costs two cross-stream hops and ~4x the host time of a
+            # synchronous call (which RCCL runs on the compute stream itself), so it is opt-in.
+            group = self.group
+            if self.syncbn_overlap:
+                pending = []
+                self._host(lambda: pending.append(dist.all_reduce(sums, group=group, async_op=True)))
+                self._run_deferred()
+                self._host(lambda: pending.pop().wait())
+            else:
+                self._host(lambda: dist.all_reduce(sums, group=group))
         return ops.bn_bwd_elemt(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, sums, 1.0 / ctx.count,
                                 mask_src, mask_mode)
+
+    def _wgrad(self, fn) -> None:
+        """Run a weight-gradient closure now, or (SyncBN) hold it back until the next statistics
+        all-reduce is in flight.  Closures run in submission order, so gradient buckets still
+        complete in the order the reducer expects."""
+        if self.sync_bn and self.syncbn_overlap:
+            self._run_deferred()
+            self._deferred = fn
+        else:
+            fn()
+
+    def _run_deferred(self) -> None:
+        fn, self._deferred = self._deferred, None
+        if fn is not None:
+            fn()
 
     def _affine_eval(self, u: ConvBNSpec) -> Tuple[torch.Tensor, torch.Tensor]:
         if self._eval_affine is None:
@@ -277,6 +324,8 @@ class NativeResNet:
         ops = self.ops
         self._ctx.clear()
         self._saved.clear()
+        if train and self._rec is None:
+            self._count_training_forward()
         with trace_range("forward"):
             x0 = ops.input_transform(img, self.mean, self.std, self.dtype)
             stem = self.spec.stem
@@ -307,6 +356,20 @@ class NativeResNet:
         return logits
 
     # ------------------------------------------------------------------ backward
+    def _conv_wgrad_fn(self, u: ConvBNSpec, x: torch.Tensor, dy: torch.Tensor):
+        P, ops, red = self.params, self.ops, self.reducer
+        key = f"{u.conv}.weight"
+
+        def run() -> None:
+            ops.conv_wgrad(x, dy, u.ksize, u.ksize, u.stride, u.pad, P.grad(key))
+            self._mark_ready(P.end_offset(key))
+        return run
+
+    def _mark_ready(self, end_offset: int) -> None:
+        red = self.reducer
+        if red.completes_bucket(end_offset):        # otherwise nothing would be launched
+            self._host(lambda: red.mark_ready(end_offset))
+
     def _block_backward(self, b: BlockSpec, g: torch.Tensor) -> torch.Tensor:
         """``g``: gradient w.r.t. the block's pre-ReLU sum, i.e. ALREADY multiplied by the mask of
         the block's output ReLU (the producer of ``g`` fuses that).  Returns the gradient w.r.t.
@@ -324,8 +387,7 @@ class NativeResNet:
             else:
                 dy = self._bn_backward(u, ctx, cur, None, MASK_RECOMPUTE)
             key = f"{u.conv}.weight"
-            ops.conv_wgrad(ctx.x_in, dy, u.ksize, u.ksize, u.stride, u.pad, P.grad(key))
-            red.mark_ready(P.end_offset(key))
+            self._wgrad(self._conv_wgrad_fn(u, ctx.x_in, dy))
             if i > 0:
                 cur = ops.conv_dgrad(dy, P.compute(key), self._wt_view(key), tuple(ctx.x_in.shape),
                                      u.ksize, u.ksize, u.stride, u.pad)
@@ -338,8 +400,7 @@ class NativeResNet:
             ctx = self._ctx.pop(d.bn)
             dyd = self._bn_backward(d, ctx, g, None, MASK_NONE)
             keyd = f"{d.conv}.weight"
-            ops.conv_wgrad(x_block, dyd, d.ksize, d.ksize, d.stride, d.pad, P.grad(keyd))
-            red.mark_ready(P.end_offset(keyd))
+            self._wgrad(self._conv_wgrad_fn(d, x_block, dyd))
             other = ops.conv_dgrad(dyd, P.compute(keyd), self._wt_view(keyd), tuple(x_block.shape),
                                    d.ksize, d.ksize, d.stride, d.pad)
         else:
@@ -352,12 +413,13 @@ class NativeResNet:
     def backward(self, dlogits: torch.Tensor) -> None:
         """Back-propagate ``dlogits``; gradients accumulate into the flat gradient buffer."""
         P, ops, red = self.params, self.ops, self.reducer
-        red.begin_step()
+        if red.enabled:
+            self._host(red.begin_step)
         with trace_range("backward"):
             pooled = self._saved.pop("pooled")
             dpooled = ops.linear_bwd(pooled, dlogits, P.compute("fc.weight"), self._fc_aux,
                                      P.grad("fc.weight"), P.grad("fc.bias"))
-            red.mark_ready(P.end_offset("fc.bias"))
+            self._mark_ready(P.end_offset("fc.bias"))
             H, W = self._saved.pop("final_hw")
             g = ops.avgpool_bwd(dpooled, H, W, relu_mask=self._saved.pop("final_out"))
             for b in reversed(self.spec.blocks):
@@ -366,18 +428,89 @@ class NativeResNet:
             da = ops.maxpool_bwd(g, self._saved.pop("pool_idx"), self._saved.pop("stem_shape"))
             ctx = self._ctx.pop(stem.bn)
             dy = self._bn_backward(stem, ctx, da, None, MASK_RECOMPUTE)
+            self._run_deferred()
             ops.stem_wgrad(ctx.x_in, dy, P.grad("conv1.weight"))
-            red.mark_ready(P.end_offset("conv1.weight"))
-        with trace_range("allreduce_wait"):
-            red.finish()
+            self._mark_ready(P.end_offset("conv1.weight"))
+        if red.enabled:
+            with trace_range("allreduce_wait"):
+                self._host(red.finish)
 
     # ------------------------------------------------------------------ steps
-    def forward_backward(self, img: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
-        """One forward + backward; returns the local mean loss (0-dim fp32 device tensor)."""
+    def _count_training_forward(self) -> None:
+        for bn in self.num_batches_tracked:
+            self.num_batches_tracked[bn] += 1
+
+    def _forward_backward_eager(self, img: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
         logits = self.forward(img, train=True)
         loss, dlogits = self.ops.softmax_ce(logits, label, 1.0)
         self.backward(dlogits)
         return loss
+
+    def forward_backward(self, img: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+        """One forward + backward; returns the local mean loss (0-dim fp32 device tensor).
+
+        With ``hip_graphs`` the second step of a batch signature is captured into a
+        :class:`.graphs.StepProgram` and every later one replays it; other signatures (the short
+        last batch of an epoch) beyond ``MAX_PLANS`` run eagerly."""
+        if not self.hip_graphs:
+            return self._forward_backward_eager(img, label)
+        key = (tuple(img.shape), img.dtype, tuple(label.shape), label.dtype)
+        plan = self._plans.get(key)
+        if plan is None:
+            seen = self._eager_seen.get(key, 0)
+            self._eager_seen[key] = seen + 1
+            if seen == 0 or len(self._plans) >= self.MAX_PLANS:
+                # the first step of a signature runs eagerly: it fills every lazily built cache
+                # (accumulators, tap tables, occupancy queries) that must not happen in a capture
+                return self._forward_backward_eager(img, label)
+            plan = self._capture_plan(img, label)
+            self._plans[key] = plan
+            if plan is None:                         # capture failed or not worthwhile: stay eager
+                self.hip_graphs = False
+                return self._forward_backward_eager(img, label)
+        static_img, static_label, loss, program = plan
+        static_img.copy_(img, non_blocking=True)
+        static_label.copy_(label, non_blocking=True)
+        self._count_training_forward()
+        with trace_range("step_graphs"):
+            program.replay()
+        return loss.clone()
+
+    MAX_PLANS = 2
+    MAX_HOST_ACTIONS = 16
+
+    def _capture_plan(self, img: torch.Tensor, label: torch.Tensor):
+        from .graphs import StepProgram
+        static_img, static_label = img.clone(), label.clone()
+        cur = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(cur)
+        program = StepProgram(self.device)
+        loss = None
+        try:
+            with torch.cuda.stream(side):
+                self._rec = program
+                program.begin()
+                try:
+                    loss = self._forward_backward_eager(static_img, static_label)
+                    program.finish()
+                finally:
+                    self._rec = None
+                    program.abort()
+        except Exception as exc:                     # noqa: BLE001 -- fall back to the eager path
+            import warnings
+            warnings.warn(f"step-graph capture failed ({type(exc).__name__}: {exc}); running eagerly")
+            self._ctx.clear()
+            self._saved.clear()
+            self._deferred = None
+            cur.wait_stream(side)
+            return None
+        cur.wait_stream(side)
+        if program.num_host_actions > self.MAX_HOST_ACTIONS and not self._force_graphs:
+            # Every graph boundary costs ~15 us of GPU idle time: a step cut into a hundred
+            # segments by per-layer collectives runs faster eagerly.
+            return None
+        return static_img, static_label, loss, program
 
     @torch.no_grad()
     def eval_step(self, img: torch.Tensor, label: torch.Tensor) -> torch.Tensor:

@@ -72,7 +72,14 @@ def _check(rc: int, what: str) -> None:
         raise HipKernelError(f"{what} failed with status {rc}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    # hundreds of launches per step: the raw-handle query is ~10x cheaper than building a
+    # torch.cuda.Stream object each time
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -215,11 +222,12 @@ def _host_mean_std(mean: torch.Tensor, std: torch.Tensor):
     return _ms_cache[key]
 
 
-def prepare_stem_weight(w: torch.Tensor) -> torch.Tensor:
-    """``[Co, 7, 7, 3]`` -> packed ``[Co, 7, 32]`` (k = s*4 + c, zero padded)."""
+def prepare_stem_weight(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``[Co, 7, 7, 3]`` -> packed ``[Co, 7, 32]`` (k = s*4 + c, zero padded).  ``out``: a previous
+    result to refresh in place (keeps its address, which captured graphs rely on)."""
     w = _bf16c(w, "prepare_stem_weight")
     Co = w.shape[0]
-    wp = torch.empty(Co, 7, 32, dtype=torch.bfloat16, device=w.device)
+    wp = out if out is not None else torch.empty(Co, 7, 32, dtype=torch.bfloat16, device=w.device)
     _check(_lib.pdt_stem_pack(_p(w), _p(wp), Co, _stream()), "pdt_stem_pack")
     return wp
 
@@ -436,11 +444,12 @@ def _npad(n: int) -> int:
     return (n + 63) // 64 * 64
 
 
-def prepare_fc(w: torch.Tensor) -> torch.Tensor:
-    """``w[N, K]`` -> zero-padded transposed copy ``wt[K, Npad]`` for the classifier's data gradient."""
+def prepare_fc(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``w[N, K]`` -> zero-padded transposed copy ``wt[K, Npad]`` for the classifier's data gradient
+    (``out``: refresh a previous result in place)."""
     w = _bf16c(w, "prepare_fc")
     N, K = w.shape
-    wt = torch.empty(K, _npad(N), dtype=torch.bfloat16, device=w.device)
+    wt = out if out is not None else torch.empty(K, _npad(N), dtype=torch.bfloat16, device=w.device)
     _check(_lib.pdt_transpose_w(_p(w), _p(wt), N, 1, K, _npad(N), _stream()), "pdt_transpose_w")
     return wt
 

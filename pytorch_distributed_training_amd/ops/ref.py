@@ -73,7 +73,7 @@ def input_transform(img: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, dt
     return _nhwc(img.float()).to(dtype)
 
 
-def prepare_stem_weight(w: torch.Tensor) -> torch.Tensor:
+def prepare_stem_weight(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Compute-side stem weights from the ``[64, 7, 7, 3]`` compute-dtype view (identity here)."""
     return w
 

@@ -71,6 +71,9 @@ def init_distributed(backend: str, dist_url: Optional[str], world_size: int, ran
             kwargs["init_method"] = dist_url
         else:
             kwargs["init_method"] = "env://"
+            if world_size == 1:          # forced one-rank group: no launcher has set the rendezvous
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29517")
         if backend == "nccl":
             try:
                 dist.init_process_group(device_id=device, **kwargs)

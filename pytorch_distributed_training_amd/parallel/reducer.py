@@ -67,6 +67,11 @@ class GradReducer:
             self._launch(self._next)
             self._next += 1
 
+    def completes_bucket(self, end_offset: int) -> bool:
+        """Would :meth:`mark_ready` launch anything?  Lets a caller that records host actions
+        (step-graph capture) skip the offsets that do not finish a bucket."""
+        return self.enabled and self._next < len(self.buckets) and self.buckets[self._next][1] <= end_offset
+
     def _launch(self, idx: int) -> None:
         start, end = self.buckets[idx]
         view = self.flat[start:end]

@@ -1,0 +1,141 @@
+"""GPU tier: HIP-graph replay of the training step equals the eager step.
+
+The step program (graphs separated by host actions) is checked with one rank and, in a
+subprocess with PDT_FORCE_COLLECTIVES=1, with every SyncBN all-reduce and gradient bucket going
+through a one-rank RCCL group between the graphs.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _make(hip_graphs, sync_bn=False, model="ResNet18"):
+    from pytorch_distributed_training_amd.engine import NativeResNet
+    from pytorch_distributed_training_amd.models import get_model, get_spec
+    from pytorch_distributed_training_amd.ops import hip
+    from pytorch_distributed_training_amd.optim.sgd import FlatSGD
+    torch.manual_seed(3)
+    dev = torch.device("cuda", 0)
+    net = NativeResNet(get_spec(model, 100), dev, hip, torch.bfloat16, sync_bn=sync_bn, bucket_cap_mb=4.0,
+                       first_bucket_mb=0.25, hip_graphs=hip_graphs)
+    net.load_state_dict(get_model(model, 100).state_dict())
+    opt = FlatSGD(net.params, hip, lr=0.02, momentum=0.9, weight_decay=1e-4)
+    return net, opt
+
+
+def _sync_state(dst, src):
+    dst.params.p.copy_(src.params.p)
+    dst.params.m.copy_(src.params.m)
+    dst.params.g.zero_()
+    dst.params.refresh_compute()
+    dst.running_mean.copy_(src.running_mean)
+    dst.running_var.copy_(src.running_var)
+    dst.refresh_derived_weights()
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
+
+
+def _compare(sync_bn, model="ResNet18", steps=6):
+    """Three engines take every step from the SAME state (the lead eager engine's): a second eager
+    engine measures the run-to-run noise of the atomics-ordered reductions, the graphed engine
+    must stay within a small multiple of it."""
+    saved = os.environ.pop("PDT_HIP_GRAPHS", None)
+    lead, opt = _make(False, sync_bn, model)
+    twin, _ = _make(False, sync_bn, model)
+    if saved is not None:
+        os.environ["PDT_HIP_GRAPHS"] = saved
+    graphed, _ = _make(True, sync_bn, model)
+    assert graphed.hip_graphs
+    g = torch.Generator().manual_seed(5)
+    worst = {"noise_grad": 0.0, "graph_grad": 0.0, "noise_loss": 0.0, "graph_loss": 0.0, "noise_rm": 0.0,
+             "graph_rm": 0.0}
+    for _ in range(steps):
+        x = torch.randint(0, 255, (16, 64, 64, 3), generator=g, dtype=torch.uint8).cuda()
+        y = torch.randint(0, 100, (16,), generator=g).cuda()
+        _sync_state(twin, lead)
+        _sync_state(graphed, lead)
+        l0 = lead.forward_backward(x, y)
+        l1 = twin.forward_backward(x, y)
+        l2 = graphed.forward_backward(x, y)
+        worst["noise_grad"] = max(worst["noise_grad"], _rel(twin.params.g, lead.params.g))
+        worst["graph_grad"] = max(worst["graph_grad"], _rel(graphed.params.g, lead.params.g))
+        worst["noise_loss"] = max(worst["noise_loss"], abs(float(l1) - float(l0)))
+        worst["graph_loss"] = max(worst["graph_loss"], abs(float(l2) - float(l0)))
+        worst["noise_rm"] = max(worst["noise_rm"], _rel(twin.running_mean, lead.running_mean))
+        worst["graph_rm"] = max(worst["graph_rm"], _rel(graphed.running_mean, lead.running_mean))
+        opt.step(grad_scale=lead.reducer.grad_scale)
+        lead.refresh_derived_weights()
+    torch.cuda.synchronize()
+    plan = next(iter(graphed._plans.values()))
+    assert plan is not None, "capture fell back to eager"
+    program = plan[3]
+    worst.update({"graphs": program.num_graphs, "host_actions": program.num_host_actions,
+                  "nbt": [lead.num_batches_tracked["bn1"], graphed.num_batches_tracked["bn1"]], "steps": steps})
+    return worst
+
+
+def _check(res):
+    assert res["graph_grad"] <= 5.0 * res["noise_grad"] + 1e-4, res
+    assert res["graph_loss"] <= 5.0 * res["noise_loss"] + 1e-4, res
+    assert res["graph_rm"] <= 5.0 * res["noise_rm"] + 1e-5, res
+    assert res["nbt"] == [res["steps"], res["steps"]], res
+
+
+def test_graph_replay_matches_eager_single_rank():
+    res = _compare(False)
+    _check(res)
+    assert res["graphs"] == 1 and res["host_actions"] == 0, res
+
+
+def test_graph_replay_bottleneck_model():
+    _check(_compare(False, "ResNet50"))
+
+
+def test_short_last_batch_gets_its_own_plan_then_eager():
+    net, opt = _make(True)
+    g = torch.Generator().manual_seed(1)
+    for batch in (16, 16, 16, 8, 8, 8, 4, 4, 16):
+        x = torch.randint(0, 255, (batch, 64, 64, 3), generator=g, dtype=torch.uint8).cuda()
+        y = torch.randint(0, 100, (batch,), generator=g).cuda()
+        loss = net.forward_backward(x, y)
+        opt.step(grad_scale=1.0)
+        net.refresh_derived_weights()
+        assert torch.isfinite(loss).item()
+    assert len([p for p in net._plans.values() if p is not None]) == 2     # 16 and 8; batch 4 stays eager
+
+
+def _forced_worker():
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", world_size=1, rank=0, device_id=torch.device("cuda", 0))
+    res = _compare(True)
+    dist.destroy_process_group()
+    print("RESULT " + json.dumps(res), flush=True)
+
+
+def test_graph_replay_with_collectives_between_graphs():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.update({"PDT_FORCE_COLLECTIVES": "1", "PDT_HIP_GRAPHS": "force", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                "PYTHONPATH": ROOT + os.pathsep + os.path.join(ROOT, "tests") + os.pathsep + env.get("PYTHONPATH", "")})
+    res = subprocess.run([sys.executable, "-c", "import test_graphs_gpu as t; t._forced_worker()"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    out = json.loads(line[len("RESULT "):])
+    _check(out)
+    # ResNet-18: 20 SyncBN layers -> 20 forward + 20 backward all-reduces, plus the reducer's
+    # begin / bucket launches / finish
+    assert out["host_actions"] >= 40 and out["graphs"] == out["host_actions"] + 1, out
