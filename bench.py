@@ -117,6 +117,9 @@ def main() -> int:
     loss = None
     for _ in range(args.warmup):
         loss = step()
+    if args.engine == "native" and not engine.model.check_comm_health():
+        for _ in range(args.warmup):              # the exchange path changed: warm the new one up
+            loss = step()
     if info.distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -160,6 +163,9 @@ def main() -> int:
                     engine.model.reducer.stats["launched"] // max(args.steps + args.warmup, 1)
                     if args.engine == "native" else None),
                 "host_submit_ms_per_step": round(1e3 * enqueue / args.steps, 3),
+                "syncbn_comm": engine.model.syncbn_comm if (args.engine == "native" and engine.model.sync_bn) else None,
+                "step_graphs": (bool(engine.model.hip_graphs and any(p is not None for p in engine.model._plans.values()))
+                                if args.engine == "native" else None),
                 "sync_bn_active": bool(engine.model.sync_bn) if args.engine == "native" else None,
             },
         }), flush=True)

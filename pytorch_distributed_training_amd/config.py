@@ -68,6 +68,7 @@ _SCHEMA: Dict[str, Any] = {
         "checkpoint_dir": (str, None),
         "resume": (str, None),
         "no_wd_bn": (bool, False),
+        "syncbn_comm": (str, "auto"),          # auto | xgmi | rccl: transport of the SyncBN statistics
         "syncbn_overlap": (bool, False),       # async BN-backward all-reduce overlapped with the previous wgrad
         "engine": (str, "native"),             # native | torch
         "max_val_batches": (int, None),

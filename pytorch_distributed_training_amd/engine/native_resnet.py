@@ -75,7 +75,7 @@ class NativeResNet:
     def __init__(self, spec: ResNetSpec, device: torch.device, ops, compute_dtype: torch.dtype = torch.bfloat16,
                  sync_bn: bool = False, group=None, bucket_cap_mb: float = 25.0, first_bucket_mb: float = 1.0,
                  overlap_comm: bool = True, bn_momentum: float = 0.1, bn_eps: float = 1e-5,
-                 hip_graphs: bool = False, syncbn_overlap: bool = False) -> None:
+                 hip_graphs: bool = False, syncbn_overlap: bool = False, syncbn_comm: str = "auto") -> None:
         self.spec = spec
         self.device = torch.device(device)
         self.ops = ops
@@ -122,6 +122,23 @@ class NativeResNet:
         self._ctx: Dict[str, _UnitCtx] = {}
         self._saved: Dict[str, object] = {}
         self._deferred = None            # weight-gradient closure held back under SyncBN (see _wgrad)
+        # SyncBN statistics exchange: the one-kernel xGMI all-reduce when it is available and has
+        # passed its self-test on this machine, else the process group's all-reduce.
+        self._xgmi = None
+        self.syncbn_comm = "rccl"
+        if self.sync_bn and self.device.type == "cuda" and getattr(ops, "name", "") == "hip" \
+                and os.environ.get("PDT_SYNCBN_COMM", syncbn_comm) in ("auto", "xgmi"):
+            from ..parallel.xgmi_allreduce import XgmiAllReduce
+            x = XgmiAllReduce.create(group, self.device)
+            if x is not None and not x.self_test():
+                x.close()
+                x = None
+            self._xgmi = x
+            self.syncbn_comm = "xgmi" if x is not None else "rccl"
+        # Fused statistics path: the conv leaves its statistics in the accumulator and ONE kernel
+        # does fold + rank exchange + finalize (needs the in-kernel exchange when SyncBN is on).
+        self._fused_stats = bool(getattr(ops, "fused_finalize", False)) and self.device.type == "cuda" \
+            and (not self.sync_bn or self._xgmi is not None) and os.environ.get("PDT_FUSED_STATS", "1") == "1"
         # Step graphs (see .graphs): one captured program per batch signature.
         env = os.environ.get("PDT_HIP_GRAPHS")       # 0 = off, 1 = on, force = on whatever the segment count
         self.hip_graphs = (bool(hip_graphs) if env is None else env in ("1", "force")) and self.device.type == "cuda"
@@ -230,22 +247,57 @@ class NativeResNet:
         else:
             self._rec.host(fn)
 
-    def _bn_train(self, u: ConvBNSpec, ctx: _UnitCtx, moments: torch.Tensor, n_local: int) -> None:
-        P = self.params
-        if self.sync_bn:
+    def _stat_all_reduce(self, t: torch.Tensor) -> None:
+        """SUM a per-layer statistics vector over the ranks (in place)."""
+        x = self._xgmi
+        if x is not None and x.supports(t):
+            x.all_reduce(t)                  # an ordinary kernel on the compute stream
+        else:
             group = self.group
-            self._host(lambda: dist.all_reduce(moments, group=group))
+            self._host(lambda: dist.all_reduce(t, group=group))
+
+    def check_comm_health(self) -> bool:
+        """Collective.  False (on every rank) when the xGMI path reported a timeout: it is then
+        dropped for the process group's all-reduce and captured step graphs are discarded."""
+        if self._xgmi is None:
+            return True
+        if self._xgmi.healthy():
+            return True
+        self._xgmi = None
+        self.syncbn_comm = "rccl"
+        self._fused_stats = False
+        self._plans.clear()
+        self._eager_seen.clear()
+        return False
+
+    def _bn_train(self, u: ConvBNSpec, ctx: _UnitCtx, stats, n_local: int) -> None:
+        """``stats``: what the conv returned -- a moments tensor, or (fused backends) the pending
+        accumulator, which one kernel folds, exchanges over the ranks and finalizes."""
+        P, ops = self.params, self.ops
+        if self.sync_bn:
             inv_world, count = 1.0 / self.world, n_local * self.world
         else:
             inv_world, count = 1.0, n_local
-        ctx.scale, ctx.shift, ctx.mean, ctx.invstd = self.ops.bn_finalize(
-            moments, inv_world, P.param(f"{u.bn}.weight"), P.param(f"{u.bn}.bias"),
-            self.rm(u.bn), self.rv(u.bn), self.bn_momentum, self.bn_eps, count)
+        args = (P.param(f"{u.bn}.weight"), P.param(f"{u.bn}.bias"), self.rm(u.bn), self.rv(u.bn),
+                self.bn_momentum, self.bn_eps, count)
+        if self._fused_stats and u.cout <= ops.FUSED_MAX_C:
+            ctx.scale, ctx.shift, ctx.mean, ctx.invstd = ops.bn_finalize_fused(
+                stats, self._xgmi if self.sync_bn else None, inv_world, *args)
+        else:
+            moments = ops.stats_to_moments(stats) if hasattr(ops, "stats_to_moments") else stats
+            if self.sync_bn:
+                self._stat_all_reduce(moments)
+            ctx.scale, ctx.shift, ctx.mean, ctx.invstd = ops.bn_finalize(moments, inv_world, *args)
         ctx.count = count
 
     def _bn_backward(self, u: ConvBNSpec, ctx: _UnitCtx, g: torch.Tensor, mask_src, mask_mode: int) -> torch.Tensor:
         """Gradient w.r.t. the raw conv output; accumulates dgamma / dbeta into the flat buffer."""
         P, ops = self.params, self.ops
+        if self.sync_bn and self._xgmi is not None and self._fused_stats:
+            sums = ops.bn_bwd_reduce(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, mask_src, mask_mode,
+                                     P.grad(f"{u.bn}.weight"), P.grad(f"{u.bn}.bias"), comm=self._xgmi)
+            return ops.bn_bwd_elemt(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, sums, 1.0 / ctx.count,
+                                    mask_src, mask_mode)
         sums = ops.bn_bwd_reduce(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, mask_src, mask_mode,
                                  P.grad(f"{u.bn}.weight"), P.grad(f"{u.bn}.bias"))
         if self.sync_bn:
@@ -255,7 +307,9 @@ class NativeResNet:
             # collective.  That costs two cross-stream hops and ~4x the host time of a
             # synchronous call (which RCCL runs on the compute stream itself), so it is opt-in.
             group = self.group
-            if self.syncbn_overlap:
+            if self._xgmi is not None and self._xgmi.supports(sums):
+                self._xgmi.all_reduce(sums)
+            elif self.syncbn_overlap:
                 pending = []
                 self._host(lambda: pending.append(dist.all_reduce(sums, group=group, async_op=True)))
                 self._run_deferred()
@@ -269,7 +323,7 @@ class NativeResNet:
         """Run a weight-gradient closure now, or (SyncBN) hold it back until the next statistics
         all-reduce is in flight.  Closures run in submission order, so gradient buckets still
         complete in the order the reducer expects."""
-        if self.sync_bn and self.syncbn_overlap:
+        if self.sync_bn and self.syncbn_overlap and self._xgmi is None:
             self._run_deferred()
             self._deferred = fn
         else:
@@ -294,7 +348,8 @@ class NativeResNet:
                       train: bool) -> torch.Tensor:
         ops = self.ops
         w = self.params.compute(f"{u.conv}.weight")
-        y, moments = ops.conv_fprop(x, w, u.ksize, u.ksize, u.stride, u.pad, self.rm(u.bn) if train else None)
+        kw = {"defer_stats": True} if (train and self._fused_stats) else {}
+        y, moments = ops.conv_fprop(x, w, u.ksize, u.ksize, u.stride, u.pad, self.rm(u.bn) if train else None, **kw)
         if train:
             ctx = _UnitCtx()
             ctx.x_in, ctx.y = x, y
@@ -329,7 +384,8 @@ class NativeResNet:
         with trace_range("forward"):
             x0 = ops.input_transform(img, self.mean, self.std, self.dtype)
             stem = self.spec.stem
-            y, moments = ops.stem_fprop(x0, self._stem_w, self.rm(stem.bn) if train else None)
+            kw = {"defer_stats": True} if (train and self._fused_stats) else {}
+            y, moments = ops.stem_fprop(x0, self._stem_w, self.rm(stem.bn) if train else None, **kw)
             if train:
                 ctx = _UnitCtx()
                 ctx.x_in, ctx.y = x0, y

@@ -21,7 +21,7 @@ CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libpdt_hip.so")
 ARCH = "gfx950"
-SOURCES = ["elementwise.hip", "reduce.hip", "conv_igemm.hip", "conv_wgrad.hip"]
+SOURCES = ["elementwise.hip", "reduce.hip", "conv_igemm.hip", "conv_wgrad.hip", "xgmi_allreduce.hip"]
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wno-unused-result"]
 
 

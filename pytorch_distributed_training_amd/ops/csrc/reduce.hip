@@ -15,8 +15,23 @@
 // keeps running means identical on all ranks -- the shifted moments of different ranks can be
 // averaged by ONE all-reduce.
 #include "common.h"
+#include "xgmi_exchange.h"
 
 #define NREP 16
+
+// The replicated accumulators are written by device-scope float atomics from every XCD.  Folding
+// and re-zeroing them goes through device-scope (cache-coherent across the XCDs' L2s) accesses as
+// well, so their correctness never depends on which cache maintenance a kernel boundary performs
+// (a launch from a captured graph may do less of it than a stream launch).
+__global__ void zero_floats_kernel(float* p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0.0f;
+}
+
+__device__ __forceinline__ float acc_take(float* p) {
+    float v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
 
 // ------------------------------------------------------------------------------------------
 // Column reduce skeleton
@@ -109,10 +124,7 @@ __global__ __launch_bounds__(256) void bn_moments_kernel(float* __restrict__ acc
     if (i >= 2 * C) return;
     float s = 0.0f;
 #pragma unroll
-    for (int r = 0; r < NREP; ++r) {
-        s += acc[(size_t)r * 2 * C + i];
-        acc[(size_t)r * 2 * C + i] = 0.0f;
-    }
+    for (int r = 0; r < NREP; ++r) s += acc_take(acc + (size_t)r * 2 * C + i);
     moments[i] = s * inv_count;
 }
 
@@ -151,6 +163,62 @@ PDT_API int pdt_bn_finalize(const float* moments, float inv_world, const float* 
                             float* shift, float* mean_out, float* invstd_out, int C, hipStream_t s) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, moments, inv_world, gamma, beta, rmean,
                        rvar, momentum, eps, unbias, scale, shift, mean_out, invstd_out, C);
+    return pdt_launch_status();
+}
+
+// ---- fused: replicas -> local moments -> [exchange over the ranks] -> finalize ----------------
+// One block; replaces bn_moments + (all-reduce) + bn_finalize, i.e. two or three dependent tiny
+// launches on the critical path of every layer.  ``use_car`` selects the xGMI exchange.
+__global__ __launch_bounds__(1024) void bn_finalize_fused_kernel(
+    const CarDev car, int use_car, float* __restrict__ acc, float inv_count, float inv_world,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+    float* __restrict__ rvar, float momentum, float eps, float unbias, float* __restrict__ scale,
+    float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out, int C) {
+    __shared__ float vals[CAR_MAX_FLOATS];
+    __shared__ unsigned ctl[2];
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        float s = 0.0f;
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) s += acc_take(acc + (size_t)r * 2 * C + i);
+        vals[i] = s * inv_count;
+    }
+    __syncthreads();
+    if (use_car && !car_exchange_block(car, vals, 2 * C, ctl)) return;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = rmean[c];
+        float m0 = vals[c] * inv_world;
+        float m1 = vals[C + c] * inv_world;
+        float mean = s + m0;
+        float var = fmaxf(m1 - m0 * m0, 0.0f);
+        float invstd = rsqrtf(var + eps);
+        float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - mean * sc;
+        mean_out[c] = mean;
+        invstd_out[c] = invstd;
+        rmean[c] = (1.0f - momentum) * s + momentum * mean;
+        rvar[c] = (1.0f - momentum) * rvar[c] + momentum * var * unbias;
+    }
+}
+
+static bool car_ready(const CarHost* h, int n) {
+    if (!h || n > CAR_MAX_FLOATS || n / 4 > h->dev.max4 || (n & 3)) return false;
+    for (int r = 0; r < h->dev.world; ++r)
+        if (!h->dev.peer_recv[r]) return false;
+    return true;
+}
+
+PDT_API int pdt_bn_finalize_fused(void* car, float* acc, float inv_count, float inv_world, const float* gamma,
+                                  const float* beta, float* rmean, float* rvar, float momentum, float eps,
+                                  float unbias, float* scale, float* shift, float* mean_out, float* invstd_out, int C,
+                                  hipStream_t s) {
+    if (C < 1 || 2 * C > CAR_MAX_FLOATS) return -1;
+    const CarHost* h = static_cast<const CarHost*>(car);
+    if (h && !car_ready(h, 2 * C)) return -3;
+    CarDev dev = h ? h->dev : CarDev{};
+    int threads = C >= 512 ? 1024 : 256;
+    hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3(1), dim3(threads), 0, s, dev, h ? 1 : 0, acc, inv_count, inv_world,
+                       gamma, beta, rmean, rvar, momentum, eps, unbias, scale, shift, mean_out, invstd_out, C);
     return pdt_launch_status();
 }
 
@@ -244,16 +312,50 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(float* __restrict__ ac
 #pragma unroll
     for (int r = 0; r < NREP; ++r) {
         size_t base = (size_t)r * 2 * C;
-        s0 += acc[base + c];
-        s1 += acc[base + C + c];
-        acc[base + c] = 0.0f;
-        acc[base + C + c] = 0.0f;
+        s0 += acc_take(acc + base + c);
+        s1 += acc_take(acc + base + C + c);
     }
     s1 *= invstd[c];
     sums[c] = s0;
     sums[C + c] = s1;
     if (dbeta) dbeta[c] += s0;
     if (dgamma) dgamma[c] += s1;
+}
+
+// fused: replicas -> local sums (+ local dgamma / dbeta) -> exchange over the ranks -> sums
+__global__ __launch_bounds__(1024) void bn_bwd_sums_fused_kernel(const CarDev car, float* __restrict__ acc,
+                                                                  const float* __restrict__ invstd,
+                                                                  float* __restrict__ sums, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta, int C) {
+    __shared__ float vals[CAR_MAX_FLOATS];
+    __shared__ unsigned ctl[2];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) {
+            size_t base = (size_t)r * 2 * C;
+            s0 += acc_take(acc + base + c);
+            s1 += acc_take(acc + base + C + c);
+        }
+        s1 *= invstd[c];
+        vals[c] = s0;
+        vals[C + c] = s1;
+        if (dbeta) dbeta[c] += s0;          // local: the gradient buckets are summed over the ranks later
+        if (dgamma) dgamma[c] += s1;
+    }
+    __syncthreads();
+    if (!car_exchange_block(car, vals, 2 * C, ctl)) return;
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sums[i] = vals[i];
+}
+
+PDT_API int pdt_bn_bwd_sums_fused(void* car, float* acc, const float* invstd, float* sums, float* dgamma,
+                                  float* dbeta, int C, hipStream_t s) {
+    const CarHost* h = static_cast<const CarHost*>(car);
+    if (C < 1 || !car_ready(h, 2 * C)) return -3;
+    int threads = C >= 512 ? 1024 : 256;
+    hipLaunchKernelGGL(bn_bwd_sums_fused_kernel, dim3(1), dim3(threads), 0, s, h->dev, acc, invstd, sums, dgamma, dbeta,
+                       C);
+    return pdt_launch_status();
 }
 
 PDT_API int pdt_bn_bwd_sums(float* acc, const float* invstd, float* sums, float* dgamma, float* dbeta, int C,
@@ -318,8 +420,9 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const bf16* __restrict_
 PDT_API int pdt_softmax_ce(const void* logits, const void* labels, void* dlogits, float* loss, int B, int N,
                            int ld_in, int ld_out, float gscale, hipStream_t s) {
     if (N > 64 * CE_REG || ld_out > 64 * CE_REG) return -1;
-    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
+    // zeroed by a kernel, not a memset: inside a captured graph a memset node was seen to run
+    // out of order with the kernel that accumulates into the same word
+    hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, s, loss, 1);
     hipLaunchKernelGGL(softmax_ce_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, (const bf16*)logits,
                        (const long long*)labels, (bf16*)dlogits, loss, B, N, ld_in, ld_out, gscale);
     return pdt_launch_status();
@@ -365,8 +468,7 @@ __global__ __launch_bounds__(256) void ce_metrics_kernel(const bf16* __restrict_
 PDT_API int pdt_ce_metrics(const void* logits, const void* labels, float* out, int B, int N, int ld_in,
                            hipStream_t s) {
     if (N > 64 * CE_REG) return -1;
-    hipError_t e = hipMemsetAsync(out, 0, 4 * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, s, out, 4);
     hipLaunchKernelGGL(ce_metrics_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, (const bf16*)logits,
                        (const long long*)labels, out, B, N, ld_in);
     return pdt_launch_status();

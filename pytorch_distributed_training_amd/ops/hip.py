@@ -58,6 +58,15 @@ _sig("pdt_bn_bwd_sums", _vp, _vp, _vp, _vp, _vp, _i, _vp)
 _sig("pdt_softmax_ce", _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp)
 _sig("pdt_ce_metrics", _vp, _vp, _vp, _i, _i, _i, _vp)
 _sig("pdt_colsum_add", _vp, _vp, _i, _i, _i, _vp)
+_sig("pdt_bn_finalize_fused", _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _vp)
+_sig("pdt_bn_bwd_sums_fused", _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp)
+_sig("pdt_car_create", _i, _i, _i, ctypes.POINTER(ctypes.c_void_p))
+_sig("pdt_car_ipc_handle", _vp, _vp)
+_sig("pdt_car_open", _vp, _vp)
+_sig("pdt_car_set_timeout_ms", _vp, _i)
+_sig("pdt_car_allreduce", _vp, _vp, _i, _vp)
+_sig("pdt_car_query", _vp, _vp)
+_sig("pdt_car_destroy", _vp)
 _sig("pdt_conv_igemm", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
      _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp)
 _sig("pdt_conv_wgrad", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp)
@@ -180,6 +189,47 @@ def _wgrad(dy, inp, dw, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow, tap
     _check(rc, "pdt_conv_wgrad")
 
 
+class PendingStats:
+    """Per-channel statistics still sitting in the replicated accumulator a conv epilogue filled:
+    consumed either by :func:`bn_finalize_fused` (one kernel: moments, rank exchange, finalize)
+    or turned into a moments tensor by :func:`stats_to_moments`."""
+
+    __slots__ = ("acc", "C", "count")
+
+    def __init__(self, acc: torch.Tensor, C: int, count: int) -> None:
+        self.acc, self.C, self.count = acc, C, count
+
+
+fused_finalize = True       # this backend offers bn_finalize_fused / defer_stats
+FUSED_MAX_C = 2048
+
+
+def stats_to_moments(stats) -> torch.Tensor:
+    if isinstance(stats, PendingStats):
+        return _moments_from_acc(stats.acc, stats.C, stats.count)
+    return stats
+
+
+def _comm_handle(comm):
+    return None if comm is None else comm._h
+
+
+def bn_finalize_fused(stats: PendingStats, comm, inv_world: float, gamma, beta, running_mean, running_var,
+                      momentum: float, eps: float, count: int):
+    """``bn_moments`` + (all-reduce over the ranks of ``comm``, an ``XgmiAllReduce``) + ``bn_finalize``
+    in one launch.  ``count`` is the GLOBAL element count; returns ``(scale, shift, mean, invstd)``."""
+    C = stats.C
+    out = torch.empty(4, C, dtype=torch.float32, device=gamma.device)
+    unbias = float(count) / float(max(count - 1, 1))
+    rc = _lib.pdt_bn_finalize_fused(_comm_handle(comm), _p(stats.acc), 1.0 / float(stats.count), inv_world, _p(gamma),
+                                    _p(beta), _p(running_mean), _p(running_var), momentum, eps, unbias, _p(out[0]),
+                                    _p(out[1]), _p(out[2]), _p(out[3]), C, _stream())
+    _check(rc, "pdt_bn_finalize_fused")
+    if comm is not None:
+        comm.calls += 1
+    return out[0], out[1], out[2], out[3]
+
+
 def _moments_from_acc(acc: torch.Tensor, C: int, count: int) -> torch.Tensor:
     moments = torch.empty(2, C, dtype=torch.float32, device=acc.device)
     _check(_lib.pdt_bn_moments(_p(acc), _p(moments), C, 1.0 / float(count), _stream()), "pdt_bn_moments")
@@ -239,7 +289,7 @@ def _stem_geometry(x0: torch.Tensor):
     return B, Hp, Wp, Ho, Wo
 
 
-def stem_fprop(x0: torch.Tensor, wp: torch.Tensor, stat_shift: Optional[torch.Tensor]):
+def stem_fprop(x0: torch.Tensor, wp: torch.Tensor, stat_shift: Optional[torch.Tensor], defer_stats: bool = False):
     B, Hp, Wp, Ho, Wo = _stem_geometry(x0)
     Co = wp.shape[0]
     y = torch.empty(B, Ho, Wo, Co, dtype=torch.bfloat16, device=x0.device)
@@ -247,8 +297,9 @@ def stem_fprop(x0: torch.Tensor, wp: torch.Tensor, stat_shift: Optional[torch.Te
     acc = _accumulator(x0.device, Co, "stats") if stat_shift is not None else None
     _igemm(x0, wp, y, M, Hp, Wp, 4, 32, Ho, Wo, 2, Ho, Wo, 1, 0, 0, Co, Co, 7 * 32, _stem_taps(),
            stat_acc=acc, stat_shift=stat_shift)
-    moments = _moments_from_acc(acc, Co, M) if acc is not None else None
-    return y, moments
+    if acc is None:
+        return y, None
+    return y, (PendingStats(acc, Co, M) if defer_stats else _moments_from_acc(acc, Co, M))
 
 
 def stem_wgrad(x0: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) -> None:
@@ -262,7 +313,7 @@ def stem_wgrad(x0: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) -> None:
 
 # --------------------------------------------------------------------------- convolution
 def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pad: int,
-               stat_shift: Optional[torch.Tensor] = None, tile: int = 0):
+               stat_shift: Optional[torch.Tensor] = None, tile: int = 0, defer_stats: bool = False):
     x = _bf16c(x, "conv_fprop x")
     w = _bf16c(w, "conv_fprop w")
     B, Hi, Wi, Ci = x.shape
@@ -273,8 +324,9 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pa
     acc = _accumulator(x.device, Co, "stats") if stat_shift is not None else None
     _igemm(x, w, y, M, Hi, Wi, Ci, Ci, Ho, Wo, stride, Ho, Wo, 1, 0, 0, Co, Co, R * S * Ci, _fprop_taps(R, S, pad),
            stat_acc=acc, stat_shift=stat_shift, tile=tile)
-    moments = _moments_from_acc(acc, Co, M) if acc is not None else None
-    return y, moments
+    if acc is None:
+        return y, None
+    return y, (PendingStats(acc, Co, M) if defer_stats else _moments_from_acc(acc, Co, M))
 
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R: int, S: int, stride: int, pad: int,
@@ -363,7 +415,9 @@ def bn_apply(y, scale, shift, residual, relu: bool):
     return out
 
 
-def bn_bwd_reduce(g, y, mean, invstd, scale, shift, mask_src, mask_mode: int, dgamma=None, dbeta=None):
+def bn_bwd_reduce(g, y, mean, invstd, scale, shift, mask_src, mask_mode: int, dgamma=None, dbeta=None, comm=None):
+    """``comm`` (an ``XgmiAllReduce``): the returned sums are already summed over its ranks (the
+    exchange runs inside the kernel that folds the accumulator replicas)."""
     g = _bf16c(g, "bn_bwd_reduce g")
     y = _bf16c(y, "bn_bwd_reduce y")
     if mask_mode == MASK_TENSOR:
@@ -375,7 +429,15 @@ def bn_bwd_reduce(g, y, mean, invstd, scale, shift, mask_src, mask_mode: int, dg
                                       _p(scale), _p(shift), _p(acc), rows, C, mask_mode, _stream())
     _check(rc, "pdt_bn_bwd_reduce_accum")
     sums = torch.empty(2, C, dtype=torch.float32, device=y.device)
+    if comm is not None and 2 * C <= 2 * FUSED_MAX_C:
+        rc = _lib.pdt_bn_bwd_sums_fused(_comm_handle(comm), _p(acc), _p(invstd), _p(sums), _p(dgamma), _p(dbeta), C,
+                                        _stream())
+        _check(rc, "pdt_bn_bwd_sums_fused")
+        comm.calls += 1
+        return sums
     _check(_lib.pdt_bn_bwd_sums(_p(acc), _p(invstd), _p(sums), _p(dgamma), _p(dbeta), C, _stream()), "pdt_bn_bwd_sums")
+    if comm is not None:
+        comm.all_reduce(sums.view(-1))
     return sums
 
 

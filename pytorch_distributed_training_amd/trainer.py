@@ -187,6 +187,10 @@ class Trainer:
             if self.world > 1:
                 dist.all_reduce(loss_val)
             loss_val = loss_val.item() / self.world
+            health = getattr(getattr(self.engine, "model", None), "check_comm_health", None)
+            if health is not None and not health():
+                self.logger.warning("xGMI statistics exchange reported a timeout: switched to the process "
+                                    "group's all-reduce")
             lrs = self.scheduler.get_last_lr()
             self.history.append((self.iter, loss_val))
             if self.rank == 0:

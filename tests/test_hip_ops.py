@@ -173,6 +173,31 @@ def test_bn_family(hip, device, C, rows):
         assert rel_err(dx, dx_ref) < 1.5e-2
 
 
+@pytest.mark.parametrize("Ci,Co,H", [(64, 256, 14), (128, 64, 9), (256, 2048, 7)])
+def test_fused_finalize_from_conv_accumulator(hip, device, Ci, Co, H):
+    """conv (statistics left in the accumulator) + ONE fused kernel == conv + moments + finalize."""
+    torch.manual_seed(Ci + Co)
+    x = rnd(4, H, H, Ci, device=device)
+    w = rnd(Co, 1, 1, Ci, device=device, scale=0.1)
+    shift = torch.randn(Co, device=device) * 0.05
+    gamma = torch.rand(Co, device=device) + 0.5
+    beta = torch.randn(Co, device=device) * 0.1
+    rows = 4 * H * H
+    y, pend = hip.conv_fprop(x, w, 1, 1, 1, 0, stat_shift=shift, defer_stats=True)
+    assert isinstance(pend, hip.PendingStats) and pend.count == rows
+    rm, rv = shift.clone(), torch.ones(Co, device=device)
+    out = hip.bn_finalize_fused(pend, None, 1.0, gamma, beta, rm, rv, 0.1, 1e-5, rows)
+    assert float(pend.acc.abs().max()) == 0.0                       # the replicas were re-zeroed
+    mom_ref = ref.bn_stats(y, shift)
+    rm_r, rv_r = shift.clone(), torch.ones(Co, device=device)
+    out_ref = ref.bn_finalize(mom_ref, 1.0, gamma, beta, rm_r, rv_r, 0.1, 1e-5, rows)
+    for a, b in zip(list(out) + [rm, rv], list(out_ref) + [rm_r, rv_r]):
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-4)
+    # the deferred and the immediate form of the same conv agree
+    y2, mom = hip.conv_fprop(x, w, 1, 1, 1, 0, stat_shift=shift)
+    assert torch.equal(y, y2) and torch.allclose(hip.stats_to_moments(mom), mom_ref, rtol=2e-3, atol=2e-4)
+
+
 @pytest.mark.parametrize("B,H,C", [(2, 112, 64), (3, 30, 64), (1, 8, 128)])
 def test_pooling(hip, device, B, H, C):
     torch.manual_seed(B + H)
