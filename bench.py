@@ -164,7 +164,8 @@ def main() -> int:
                     if args.engine == "native" else None),
                 "host_submit_ms_per_step": round(1e3 * enqueue / args.steps, 3),
                 "syncbn_comm": engine.model.syncbn_comm if (args.engine == "native" and engine.model.sync_bn) else None,
-                "step_graphs": (bool(engine.model.hip_graphs and any(p is not None for p in engine.model._plans.values()))
+                "step_replay": ((engine.model.step_replay if engine.model.hip_graphs and
+                                 any(p is not None for p in engine.model._plans.values()) else "off")
                                 if args.engine == "native" else None),
                 "sync_bn_active": bool(engine.model.sync_bn) if args.engine == "native" else None,
             },

@@ -85,7 +85,8 @@ _SCHEMA: Dict[str, Any] = {
         "debug_sync_check": (int, 0),          # every N iters compare param hashes across ranks
         "collective_timeout_s": (int, 1800),
         "deterministic": (bool, False),
-        "hip_graphs": (bool, True),            # native engine on GPU: capture the step into HIP graphs
+        "hip_graphs": (bool, True),            # native engine on GPU: record the step once, then replay it
+        "step_replay": (str, "list"),          # list (command list of stream launches) | graph (HIP graphs) | off
     },
 }
 

@@ -51,6 +51,7 @@ class NativeEngine:
             hip_graphs=cfg.get("runtime", {}).get("hip_graphs", True),
             syncbn_overlap=tr.get("syncbn_overlap", False),
             syncbn_comm=tr.get("syncbn_comm", "auto"),
+            step_replay=cfg.get("runtime", {}).get("step_replay", "list"),
         )
         # Same-seed initialisation on every rank (upstream seeds every worker identically,
         # train_distributed.py:141-142); the eager module is only the initialiser here.

@@ -75,3 +75,52 @@ class StepProgram:
     @property
     def num_host_actions(self) -> int:
         return sum(1 for k, _ in self.items if k == "host")
+
+
+class ListProgram:
+    """The step as a flat command list: every library call the HIP backend made while the step
+    ran once (kernel launches on their streams, cross-stream waits) plus the host actions, in
+    order.  Replaying it is a loop of C calls -- ordinary stream launches, so kernels on the
+    second stream overlap as they do eagerly and collectives cost what they cost eagerly, at a
+    fraction of the host time of the Python that built the list.
+
+    The recorded step allocates from ``pool`` (a private ``torch.cuda.MemPool``): the addresses in
+    the list stay reserved for it, and re-running the list in the same order reuses them the
+    same way the recorded step did.
+    """
+
+    def __init__(self, device: torch.device, hip_ops) -> None:
+        self.device = device
+        self._ops = hip_ops
+        self.items: List[Tuple[Callable, tuple]] = []
+        self.pool = torch.cuda.MemPool()
+        self.stream = torch.cuda.current_stream(device).cuda_stream
+        self.num_host_actions = 0
+
+    def begin(self) -> None:
+        self._ops.begin_recording(self.items)
+
+    def host(self, fn: Callable[[], None]) -> None:
+        fn()
+        self.items.append((fn, ()))
+        self.num_host_actions += 1
+
+    def finish(self) -> None:
+        self._ops.end_recording()
+
+    abort = finish
+
+    def replay(self) -> None:
+        if torch.cuda.current_stream(self.device).cuda_stream != self.stream:
+            raise RuntimeError("a recorded step must be replayed on the stream it was recorded on")
+        for fn, args in self.items:
+            if fn(*args):
+                raise RuntimeError(f"replayed call {getattr(fn, '__name__', fn)} failed")
+
+    @property
+    def num_graphs(self) -> int:
+        return 0
+
+    @property
+    def num_calls(self) -> int:
+        return len(self.items) - self.num_host_actions

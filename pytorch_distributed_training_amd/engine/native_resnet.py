@@ -75,7 +75,8 @@ class NativeResNet:
     def __init__(self, spec: ResNetSpec, device: torch.device, ops, compute_dtype: torch.dtype = torch.bfloat16,
                  sync_bn: bool = False, group=None, bucket_cap_mb: float = 25.0, first_bucket_mb: float = 1.0,
                  overlap_comm: bool = True, bn_momentum: float = 0.1, bn_eps: float = 1e-5,
-                 hip_graphs: bool = False, syncbn_overlap: bool = False, syncbn_comm: str = "auto") -> None:
+                 hip_graphs: bool = False, syncbn_overlap: bool = False, syncbn_comm: str = "auto",
+                 step_replay: str = "list") -> None:
         self.spec = spec
         self.device = torch.device(device)
         self.ops = ops
@@ -122,6 +123,9 @@ class NativeResNet:
         self._ctx: Dict[str, _UnitCtx] = {}
         self._saved: Dict[str, object] = {}
         self._deferred = None            # weight-gradient closure held back under SyncBN (see _wgrad)
+        self._wgrad_stream = None        # second stream for the weight-gradient kernels (GPU only)
+        self._wgrad_keep: List[tuple] = []
+        self._fork_event = self._join_event = None
         # SyncBN statistics exchange: the one-kernel xGMI all-reduce when it is available and has
         # passed its self-test on this machine, else the process group's all-reduce.
         self._xgmi = None
@@ -139,11 +143,26 @@ class NativeResNet:
         # does fold + rank exchange + finalize (needs the in-kernel exchange when SyncBN is on).
         self._fused_stats = bool(getattr(ops, "fused_finalize", False)) and self.device.type == "cuda" \
             and (not self.sync_bn or self._xgmi is not None) and os.environ.get("PDT_FUSED_STATS", "1") == "1"
-        # Step graphs (see .graphs): one captured program per batch signature.
-        env = os.environ.get("PDT_HIP_GRAPHS")       # 0 = off, 1 = on, force = on whatever the segment count
-        self.hip_graphs = (bool(hip_graphs) if env is None else env in ("1", "force")) and self.device.type == "cuda"
+        # Step replay (see .graphs): the second step of a batch signature is recorded, later ones
+        # replay the record.  "list": a command list of the backend's own launches (default);
+        # "graph": HIP graphs separated by host actions.  PDT_HIP_GRAPHS: 0 = off, 1 = on,
+        # force = graphs whatever the number of segments; PDT_STEP_REPLAY overrides the mode.
+        env = os.environ.get("PDT_HIP_GRAPHS")
+        on = (bool(hip_graphs) if env is None else env in ("1", "force")) and self.device.type == "cuda" \
+            and getattr(ops, "name", "") == "hip"
         self._force_graphs = env == "force"
-        self._rec = None                 # StepProgram being captured, else None
+        mode = os.environ.get("PDT_STEP_REPLAY", "graph" if self._force_graphs else step_replay)
+        if mode not in ("list", "graph", "off"):
+            raise ValueError(f"step_replay must be list, graph or off, not {mode!r}")
+        self.step_replay = mode if on else "off"
+        self.hip_graphs = self.step_replay != "off"
+        # Weight gradients on a second stream: pays with stream launches (eager or "list"), not
+        # inside HIP graphs, whose parallel branches launch slowly.
+        want_ws = os.environ.get("PDT_WGRAD_STREAM", "1" if self.step_replay == "list" else "0") == "1"
+        if want_ws and self.device.type == "cuda" and getattr(ops, "name", "") == "hip":
+            self._wgrad_stream = torch.cuda.Stream(device=self.device)
+            self._fork_event, self._join_event = ops.new_event(), ops.new_event()
+        self._rec = None                 # program being recorded (StepProgram / ListProgram), else None
         self._plans: Dict[tuple, object] = {}
         self._eager_seen: Dict[tuple, int] = {}
         self.refresh_derived_weights()
@@ -417,9 +436,29 @@ class NativeResNet:
         key = f"{u.conv}.weight"
 
         def run() -> None:
-            ops.conv_wgrad(x, dy, u.ksize, u.ksize, u.stride, u.pad, P.grad(key))
-            self._mark_ready(P.end_offset(key))
+            end = P.end_offset(key)
+            ws = self._wgrad_stream
+            if ws is None:
+                ops.conv_wgrad(x, dy, u.ksize, u.ksize, u.stride, u.pad, P.grad(key))
+            else:
+                # The weight gradient is off the critical path (only the optimiser and the bucket
+                # all-reduce wait for it): on a second stream it fills the slots the data-gradient
+                # kernels leave idle in their last, partial round of tiles.
+                cur = torch.cuda.current_stream(self.device).cuda_stream
+                ops.stream_wait_stream(ws.cuda_stream, cur, self._fork_event)
+                with torch.cuda.stream(ws):
+                    ops.conv_wgrad(x, dy, u.ksize, u.ksize, u.stride, u.pad, P.grad(key))
+                self._wgrad_keep.append((x, dy))       # their memory must outlive the side-stream kernel
+                if red.completes_bucket(end):
+                    self._join_wgrad()
+            self._mark_ready(end)
         return run
+
+    def _join_wgrad(self) -> None:
+        if self._wgrad_stream is not None and self._wgrad_keep:
+            cur = torch.cuda.current_stream(self.device).cuda_stream
+            self.ops.stream_wait_stream(cur, self._wgrad_stream.cuda_stream, self._join_event)
+            self._wgrad_keep.clear()
 
     def _mark_ready(self, end_offset: int) -> None:
         red = self.reducer
@@ -485,6 +524,7 @@ class NativeResNet:
             ctx = self._ctx.pop(stem.bn)
             dy = self._bn_backward(stem, ctx, da, None, MASK_RECOMPUTE)
             self._run_deferred()
+            self._join_wgrad()
             ops.stem_wgrad(ctx.x_in, dy, P.grad("conv1.weight"))
             self._mark_ready(P.end_offset("conv1.weight"))
         if red.enabled:
@@ -505,9 +545,9 @@ class NativeResNet:
     def forward_backward(self, img: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
         """One forward + backward; returns the local mean loss (0-dim fp32 device tensor).
 
-        With ``hip_graphs`` the second step of a batch signature is captured into a
-        :class:`.graphs.StepProgram` and every later one replays it; other signatures (the short
-        last batch of an epoch) beyond ``MAX_PLANS`` run eagerly."""
+        With step replay the second step of a batch signature is recorded (command list) or
+        captured (HIP graphs) and every later one replays it; signatures beyond ``MAX_PLANS``
+        (the short last batch of an epoch is the second) run eagerly."""
         if not self.hip_graphs:
             return self._forward_backward_eager(img, label)
         key = (tuple(img.shape), img.dtype, tuple(label.shape), label.dtype)
@@ -519,8 +559,15 @@ class NativeResNet:
                 # the first step of a signature runs eagerly: it fills every lazily built cache
                 # (accumulators, tap tables, occupancy queries) that must not happen in a capture
                 return self._forward_backward_eager(img, label)
-            plan = self._capture_plan(img, label)
-            self._plans[key] = plan
+            if self.step_replay == "list":
+                plan = self._record_plan(img, label)
+                self._plans[key] = plan
+                if plan is not None:                 # recording ran the step for real
+                    self._count_training_forward()
+                    return plan[2].clone()
+            else:
+                plan = self._capture_plan(img, label)
+                self._plans[key] = plan
             if plan is None:                         # capture failed or not worthwhile: stay eager
                 self.hip_graphs = False
                 return self._forward_backward_eager(img, label)
@@ -528,9 +575,33 @@ class NativeResNet:
         static_img.copy_(img, non_blocking=True)
         static_label.copy_(label, non_blocking=True)
         self._count_training_forward()
-        with trace_range("step_graphs"):
+        with trace_range("step_replay"):
             program.replay()
         return loss.clone()
+
+    def _record_plan(self, img: torch.Tensor, label: torch.Tensor):
+        """Run one step for real while the backend records every call it makes."""
+        from .graphs import ListProgram
+        program = ListProgram(self.device, self.ops)
+        static_img, static_label = img.clone(), label.clone()
+        try:
+            with torch.cuda.use_mem_pool(program.pool):
+                self._rec = program
+                program.begin()
+                try:
+                    loss = self._forward_backward_eager(static_img, static_label)
+                finally:
+                    self._rec = None
+                    program.finish()
+        except Exception as exc:                     # noqa: BLE001 -- fall back to the eager path
+            import warnings
+            warnings.warn(f"step recording failed ({type(exc).__name__}: {exc}); running eagerly")
+            self._ctx.clear()
+            self._saved.clear()
+            self._deferred = None
+            self._wgrad_keep.clear()
+            return None
+        return static_img, static_label, loss, program
 
     MAX_PLANS = 2
     MAX_HOST_ACTIONS = 16

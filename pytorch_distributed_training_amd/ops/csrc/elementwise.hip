@@ -442,3 +442,37 @@ PDT_API int pdt_stem_unpack_add(const float* dwp, float* dw, int Co, hipStream_t
     hipLaunchKernelGGL(stem_unpack_add_kernel, dim3(cdiv(Co * 147, 256)), dim3(256), 0, s, dwp, dw, Co);
     return pdt_launch_status();
 }
+
+
+// ---- small runtime helpers (kept behind the C ABI so a recorded step can replay them) ---------
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = 0.0f;
+}
+
+PDT_API int pdt_zero_f32(float* p, long long n, hipStream_t s) {
+    if (n <= 0) return 0;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, n);
+    return pdt_launch_status();
+}
+
+PDT_API int pdt_event_create(void** out) {
+    hipEvent_t ev;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return (int)e;
+    *out = (void*)ev;
+    return 0;
+}
+
+PDT_API int pdt_event_destroy(void* ev) { return ev ? (int)hipEventDestroy((hipEvent_t)ev) : 0; }
+
+// Work enqueued on `waiter` after this call starts only when everything enqueued on `waited`
+// before it has finished.
+PDT_API int pdt_stream_wait_stream(hipStream_t waiter, hipStream_t waited, void* ev) {
+    hipError_t e = hipEventRecord((hipEvent_t)ev, waited);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipStreamWaitEvent(waiter, (hipEvent_t)ev, 0);
+}

@@ -19,19 +19,26 @@
 
 #define NREP 16
 
-// The replicated accumulators are written by device-scope float atomics from every XCD.  Folding
-// and re-zeroing them goes through device-scope (cache-coherent across the XCDs' L2s) accesses as
-// well, so their correctness never depends on which cache maintenance a kernel boundary performs
-// (a launch from a captured graph may do less of it than a stream launch).
+// Fold the NREP replicas of accumulator element i (row stride `stride`) and re-zero them.  All
+// loads are issued before the first store so they overlap (a load/store pair per replica
+// serialises on the load latency).
+__device__ __forceinline__ float acc_take(float* p, size_t stride) {
+    float v[NREP];
+#pragma unroll
+    for (int r = 0; r < NREP; ++r) v[r] = p[(size_t)r * stride];
+    float s = 0.0f;
+#pragma unroll
+    for (int r = 0; r < NREP; ++r) {
+        s += v[r];
+        p[(size_t)r * stride] = 0.0f;
+    }
+    return s;
+}
+
 __global__ void zero_floats_kernel(float* p, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0.0f;
 }
 
-__device__ __forceinline__ float acc_take(float* p) {
-    float v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(p, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return v;
-}
 
 // ------------------------------------------------------------------------------------------
 // Column reduce skeleton
@@ -122,10 +129,7 @@ __global__ __launch_bounds__(256) void bn_moments_kernel(float* __restrict__ acc
                                                           float inv_count) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 2*C
     if (i >= 2 * C) return;
-    float s = 0.0f;
-#pragma unroll
-    for (int r = 0; r < NREP; ++r) s += acc_take(acc + (size_t)r * 2 * C + i);
-    moments[i] = s * inv_count;
+    moments[i] = acc_take(acc + i, (size_t)2 * C) * inv_count;
 }
 
 PDT_API int pdt_bn_moments(float* acc, float* moments, int C, float inv_count, hipStream_t s) {
@@ -177,10 +181,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_fused_kernel(
     __shared__ float vals[CAR_MAX_FLOATS];
     __shared__ unsigned ctl[2];
     for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
-        float s = 0.0f;
-#pragma unroll
-        for (int r = 0; r < NREP; ++r) s += acc_take(acc + (size_t)r * 2 * C + i);
-        vals[i] = s * inv_count;
+        vals[i] = acc_take(acc + i, (size_t)2 * C) * inv_count;
     }
     __syncthreads();
     if (use_car && !car_exchange_block(car, vals, 2 * C, ctl)) return;
@@ -216,7 +217,7 @@ PDT_API int pdt_bn_finalize_fused(void* car, float* acc, float inv_count, float 
     const CarHost* h = static_cast<const CarHost*>(car);
     if (h && !car_ready(h, 2 * C)) return -3;
     CarDev dev = h ? h->dev : CarDev{};
-    int threads = C >= 512 ? 1024 : 256;
+    int threads = 2 * C >= 1024 ? 1024 : (2 * C >= 256 ? 2 * C : 256);     // one accumulator element per thread
     hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3(1), dim3(threads), 0, s, dev, h ? 1 : 0, acc, inv_count, inv_world,
                        gamma, beta, rmean, rvar, momentum, eps, unbias, scale, shift, mean_out, invstd_out, C);
     return pdt_launch_status();
@@ -308,13 +309,8 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(float* __restrict__ ac
                                                            float* __restrict__ dbeta, int C) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float s0 = 0.0f, s1 = 0.0f;
-#pragma unroll
-    for (int r = 0; r < NREP; ++r) {
-        size_t base = (size_t)r * 2 * C;
-        s0 += acc_take(acc + base + c);
-        s1 += acc_take(acc + base + C + c);
-    }
+    float s0 = acc_take(acc + c, (size_t)2 * C);
+    float s1 = acc_take(acc + C + c, (size_t)2 * C);
     s1 *= invstd[c];
     sums[c] = s0;
     sums[C + c] = s1;
@@ -330,13 +326,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_sums_fused_kernel(const CarDev ca
     __shared__ float vals[CAR_MAX_FLOATS];
     __shared__ unsigned ctl[2];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float s0 = 0.0f, s1 = 0.0f;
-#pragma unroll
-        for (int r = 0; r < NREP; ++r) {
-            size_t base = (size_t)r * 2 * C;
-            s0 += acc_take(acc + base + c);
-            s1 += acc_take(acc + base + C + c);
-        }
+        float s0 = acc_take(acc + c, (size_t)2 * C);
+        float s1 = acc_take(acc + C + c, (size_t)2 * C);
         s1 *= invstd[c];
         vals[c] = s0;
         vals[C + c] = s1;
@@ -352,7 +343,7 @@ PDT_API int pdt_bn_bwd_sums_fused(void* car, float* acc, const float* invstd, fl
                                   float* dbeta, int C, hipStream_t s) {
     const CarHost* h = static_cast<const CarHost*>(car);
     if (C < 1 || !car_ready(h, 2 * C)) return -3;
-    int threads = C >= 512 ? 1024 : 256;
+    int threads = C >= 1024 ? 1024 : (C >= 256 ? C : 256);
     hipLaunchKernelGGL(bn_bwd_sums_fused_kernel, dim3(1), dim3(threads), 0, s, h->dev, acc, invstd, sums, dgamma, dbeta,
                        C);
     return pdt_launch_status();

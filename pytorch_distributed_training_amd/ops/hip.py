@@ -27,13 +27,13 @@ if not os.path.exists(_LIB_PATH):
         f"{_LIB_PATH} is missing: build the gfx950 kernels first with "
         "`python -m pytorch_distributed_training_amd.ops.build`"
     )
-_lib = ctypes.CDLL(_LIB_PATH)
+_real = ctypes.CDLL(_LIB_PATH)
 
 _vp, _i, _ll, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
 
 
 def _sig(fn_name: str, *argtypes) -> None:
-    fn = getattr(_lib, fn_name)
+    fn = getattr(_real, fn_name)
     fn.argtypes = list(argtypes)
     fn.restype = ctypes.c_int
 
@@ -72,8 +72,64 @@ _sig("pdt_conv_igemm", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, 
 _sig("pdt_conv_wgrad", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp)
 
 
+_sig("pdt_zero_f32", _vp, _ll, _vp)
+_sig("pdt_event_create", ctypes.POINTER(ctypes.c_void_p))
+_sig("pdt_event_destroy", _vp)
+_sig("pdt_stream_wait_stream", _vp, _vp, _vp)
+
+
 class HipKernelError(RuntimeError):
     pass
+
+
+# ---- call recording -------------------------------------------------------------------------
+# Every kernel launch of this backend is one call into the library with plain arguments (raw
+# pointers, integers, floats, a stream handle).  While ``_recording`` is a list, each call is
+# appended to it as ``(function, args)`` besides being executed; replaying the list re-issues the
+# same launches without any of the Python above it (see engine/graphs.ListProgram).  The
+# pointers stay valid because the recorded step allocates from a memory pool of its own.
+_recording = None
+
+
+class _LibProxy:
+    def __init__(self, lib) -> None:
+        self._lib = lib
+
+    def __getattr__(self, fn_name: str):
+        fn = getattr(self._lib, fn_name)
+
+        def call(*args, _fn=fn):
+            rec = _recording
+            if rec is not None:
+                rec.append((_fn, args))
+            return _fn(*args)
+
+        setattr(self, fn_name, call)       # next lookup finds the wrapper directly
+        return call
+
+
+_lib = _LibProxy(_real)
+
+
+def begin_recording(items: list) -> None:
+    global _recording
+    _recording = items
+
+
+def end_recording() -> None:
+    global _recording
+    _recording = None
+
+
+def new_event() -> int:
+    ev = ctypes.c_void_p()
+    _check(_real.pdt_event_create(ctypes.byref(ev)), "pdt_event_create")
+    return ev.value
+
+
+def stream_wait_stream(waiter: int, waited: int, event: int) -> None:
+    """``waiter`` (raw stream handle) waits for everything enqueued so far on ``waited``."""
+    _check(_lib.pdt_stream_wait_stream(waiter, waited, event), "pdt_stream_wait_stream")
 
 
 def _check(rc: int, what: str) -> None:
@@ -306,7 +362,8 @@ def stem_wgrad(x0: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) -> None:
     B, Hp, Wp, Ho, Wo = _stem_geometry(x0)
     dy = _bf16c(dy, "stem_wgrad dy")
     Co = dy.shape[-1]
-    scratch = torch.zeros(Co, 7, 32, dtype=torch.float32, device=dy.device)
+    scratch = torch.empty(Co, 7, 32, dtype=torch.float32, device=dy.device)
+    _check(_lib.pdt_zero_f32(_p(scratch), scratch.numel(), _stream()), "pdt_zero_f32")
     _wgrad(dy, x0, scratch, B * Ho * Wo, Hp, Wp, 4, 32, Ho, Wo, 2, Co, Co, 7 * 32, _stem_taps())
     _check(_lib.pdt_stem_unpack_add(_p(scratch), _p(dw), Co, _stream()), "pdt_stem_unpack_add")
 

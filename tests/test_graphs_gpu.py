@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _make(hip_graphs, sync_bn=False, model="ResNet18"):
+def _make(hip_graphs, sync_bn=False, model="ResNet18", replay="graph"):
     from pytorch_distributed_training_amd.engine import NativeResNet
     from pytorch_distributed_training_amd.models import get_model, get_spec
     from pytorch_distributed_training_amd.ops import hip
@@ -25,8 +25,8 @@ def _make(hip_graphs, sync_bn=False, model="ResNet18"):
     torch.manual_seed(3)
     dev = torch.device("cuda", 0)
     net = NativeResNet(get_spec(model, 100), dev, hip, torch.bfloat16, sync_bn=sync_bn, bucket_cap_mb=4.0,
-                       first_bucket_mb=0.25, hip_graphs=hip_graphs)
-    net.hip_graphs = bool(hip_graphs)          # whatever PDT_HIP_GRAPHS says for the rest of the process
+                       first_bucket_mb=0.25, hip_graphs=hip_graphs, step_replay=replay)
+    assert net.hip_graphs == bool(hip_graphs) and (not hip_graphs or net.step_replay == replay)
     net.load_state_dict(get_model(model, 100).state_dict())
     opt = FlatSGD(net.params, hip, lr=0.02, momentum=0.9, weight_decay=1e-4)
     return net, opt
@@ -46,7 +46,7 @@ def _rel(a, b):
     return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
 
 
-def _compare(sync_bn, model="ResNet18", steps=10):
+def _compare(sync_bn, model="ResNet18", steps=10, replay="graph"):
     """Three engines take every step from the SAME state (the lead eager engine's): a second eager
     engine is the control, the graphed engine is the subject.
 
@@ -61,11 +61,12 @@ def _compare(sync_bn, model="ResNet18", steps=10):
     gc.collect()
     torch.cuda.synchronize()
     saved = os.environ.pop("PDT_HIP_GRAPHS", None)
+    os.environ.pop("PDT_STEP_REPLAY", None)
     lead, opt = _make(False, sync_bn, model)
     twin, _ = _make(False, sync_bn, model)
     if saved is not None:
         os.environ["PDT_HIP_GRAPHS"] = saved
-    graphed, _ = _make(True, sync_bn, model)
+    graphed, _ = _make(True, sync_bn, model, replay)
     assert graphed.hip_graphs
     g = torch.Generator().manual_seed(5)
     rows = []
@@ -117,18 +118,21 @@ def _check(res):
     assert res["nbt"] == [res["steps"], res["steps"]], res
 
 
-def test_graph_replay_matches_eager_single_rank():
-    res = _compare(False)
+@pytest.mark.parametrize("replay", ["graph", "list"])
+def test_replay_matches_eager_single_rank(replay):
+    res = _compare(False, replay=replay)
     _check(res)
-    assert res["graphs"] == 1 and res["host_actions"] == 0, res
+    assert res["graphs"] == (1 if replay == "graph" else 0) and res["host_actions"] == 0, res
 
 
-def test_graph_replay_bottleneck_model():
-    _check(_compare(False, "ResNet50"))
+@pytest.mark.parametrize("replay", ["graph", "list"])
+def test_replay_bottleneck_model(replay):
+    _check(_compare(False, "ResNet50", replay=replay))
 
 
-def test_short_last_batch_gets_its_own_plan_then_eager():
-    net, opt = _make(True)
+@pytest.mark.parametrize("replay", ["graph", "list"])
+def test_short_last_batch_gets_its_own_plan_then_eager(replay):
+    net, opt = _make(True, replay=replay)
     g = torch.Generator().manual_seed(1)
     for batch in (16, 16, 16, 8, 8, 8, 4, 4, 16):
         x = torch.randint(0, 255, (batch, 64, 64, 3), generator=g, dtype=torch.uint8).cuda()
@@ -140,11 +144,11 @@ def test_short_last_batch_gets_its_own_plan_then_eager():
     assert len([p for p in net._plans.values() if p is not None]) == 2     # 16 and 8; batch 4 stays eager
 
 
-def _forced_worker():
+def _forced_worker(replay="graph"):
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", world_size=1, rank=0, device_id=torch.device("cuda", 0))
-    res = _compare(True)
+    res = _compare(True, replay=replay)
     dist.destroy_process_group()
     print("RESULT " + json.dumps(res), flush=True)
 
@@ -185,3 +189,27 @@ def test_graph_replay_with_xgmi_statistics_exchange_inside_the_graphs():
     out = json.loads(line[len("RESULT "):])
     _check(out)
     assert out["comm"] == "xgmi" and out["host_actions"] <= 16, out
+
+
+@pytest.mark.parametrize("comm", ["rccl", "xgmi"])
+def test_list_replay_with_collectives(comm):
+    """Command-list replay with every SyncBN exchange and gradient bucket live (one-rank RCCL
+    group): host actions sit in the list between the launches, the weight gradients run on the
+    second stream."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.update({"PDT_FORCE_COLLECTIVES": "1", "PDT_SYNCBN_COMM": comm, "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": str(port),
+                "PYTHONPATH": ROOT + os.pathsep + os.path.join(ROOT, "tests") + os.pathsep + env.get("PYTHONPATH", "")})
+    env.pop("PDT_HIP_GRAPHS", None)
+    env.pop("PDT_STEP_REPLAY", None)
+    res = subprocess.run([sys.executable, "-c", "import test_graphs_gpu as t; t._forced_worker('list')"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    out = json.loads(line[len("RESULT "):])
+    _check(out)
+    assert out["comm"] == comm and out["graphs"] == 0, out
+    assert (out["host_actions"] >= 40) if comm == "rccl" else (out["host_actions"] <= 16), out
