@@ -119,6 +119,7 @@ class NativeResNet:
             self.wt = torch.zeros(self.params.total, dtype=compute_dtype, device=self.device)
         self._stem_w = None
         self._fc_aux = None
+        self._tw_table = None            # (table, rows, blocks) of the batched dgrad-weight transpose
         self._eval_affine: Optional[Dict[str, Tuple[torch.Tensor, torch.Tensor]]] = None
         self._ctx: Dict[str, _UnitCtx] = {}
         self._saved: Dict[str, object] = {}
@@ -188,9 +189,20 @@ class NativeResNet:
         step or a state load): dgrad copies, the packed stem filter, the padded classifier."""
         P, ops = self.params, self.ops
         if self._needs_wt:
-            for u in self.units[1:]:
-                key = f"{u.conv}.weight"
-                ops.transpose_weights(P.compute(key), self._wt_view(key))
+            batched = getattr(ops, "transpose_weights_batched", None)
+            if batched is not None and self.device.type == "cuda":
+                if self._tw_table is None:
+                    ents = []
+                    for u in self.units[1:]:
+                        e = P.entries[f"{u.conv}.weight"]
+                        co, r, sdim, ci = e.shape
+                        ents.append((e.offset, co, r * sdim, ci))
+                    self._tw_table = ops.make_transpose_table(ents, self.device)
+                batched(P.pc, self.wt, *self._tw_table)
+            else:
+                for u in self.units[1:]:
+                    key = f"{u.conv}.weight"
+                    ops.transpose_weights(P.compute(key), self._wt_view(key))
         # refreshed in place: captured step graphs hold these addresses
         self._stem_w = ops.prepare_stem_weight(P.compute("conv1.weight"), out=self._stem_w)
         prep_fc = getattr(ops, "prepare_fc", None)

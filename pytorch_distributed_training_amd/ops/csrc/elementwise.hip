@@ -410,6 +410,47 @@ PDT_API int pdt_transpose_w(const void* w, void* wt, int Co, int T, int Ci, int 
     return pdt_launch_status();
 }
 
+// All data-gradient weight copies in ONE launch.  Every conv weight sits at the same element
+// offset in the flat compute mirror (w_base, [Co][T][Ci]) and in the flat transposed buffer
+// (wt_base, [Ci][T][Co]); table row e = {offset, Co, T, Ci, first_block, n_blocks}; a block covers
+// TW_PER_BLOCK consecutive output elements of its entry.
+#define TW_PER_BLOCK 2048
+__global__ __launch_bounds__(256) void transpose_w_batched_kernel(const bf16* __restrict__ w_base,
+                                                                   bf16* __restrict__ wt_base,
+                                                                   const int* __restrict__ table, int n_entries) {
+    const int b = blockIdx.x;
+    int lo = 0, hi = n_entries - 1;           // last entry whose first_block <= b
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 6 + 4] <= b) lo = mid; else hi = mid - 1;
+    }
+    const int* e = table + lo * 6;
+    const int off = e[0], Co = e[1], T = e[2], Ci = e[3], first = e[4];
+    const bf16* w = w_base + off;
+    bf16* wt = wt_base + off;
+    const int total = Ci * T * Co;
+    const int start = (b - first) * TW_PER_BLOCK;
+#pragma unroll
+    for (int k = 0; k < TW_PER_BLOCK / 256; ++k) {
+        int i = start + k * 256 + threadIdx.x;
+        if (i < total) {
+            int co = i % Co;
+            int t2 = i / Co;
+            int t = t2 % T;
+            int ci = t2 / T;
+            wt[i] = w[(co * T + t) * Ci + ci];
+        }
+    }
+}
+
+PDT_API int pdt_transpose_w_batched(const void* w_base, void* wt_base, const int* table, int n_entries,
+                                    int total_blocks, hipStream_t s) {
+    if (n_entries <= 0 || total_blocks <= 0) return 0;
+    hipLaunchKernelGGL(transpose_w_batched_kernel, dim3(total_blocks), dim3(256), 0, s, (const bf16*)w_base,
+                       (bf16*)wt_base, table, n_entries);
+    return pdt_launch_status();
+}
+
 __global__ __launch_bounds__(256) void stem_pack_kernel(const bf16* __restrict__ w, bf16* __restrict__ wp, int Co) {
     int total = Co * 7 * 32;
     int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -72,6 +72,7 @@ _sig("pdt_conv_igemm", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, 
 _sig("pdt_conv_wgrad", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp)
 
 
+_sig("pdt_transpose_w_batched", _vp, _vp, _vp, _i, _i, _vp)
 _sig("pdt_zero_f32", _vp, _ll, _vp)
 _sig("pdt_event_create", ctypes.POINTER(ctypes.c_void_p))
 _sig("pdt_event_destroy", _vp)
@@ -428,6 +429,28 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, R: int, S: int, stride: int, p
 def transpose_weights(w: torch.Tensor, wt: torch.Tensor) -> None:
     Co, R, S, Ci = w.shape
     _check(_lib.pdt_transpose_w(_p(w), _p(wt), Co, R * S, Ci, Co, _stream()), "pdt_transpose_w")
+
+
+TW_PER_BLOCK = 2048
+
+
+def make_transpose_table(entries, device: torch.device):
+    """``entries``: (flat element offset, Co, T, Ci) per conv weight -> (int32 device table, rows, blocks)."""
+    rows, first = [], 0
+    for off, Co, T, Ci in entries:
+        nb = (Co * T * Ci + TW_PER_BLOCK - 1) // TW_PER_BLOCK
+        rows.append([off, Co, T, Ci, first, nb])
+        first += nb
+    table = torch.tensor(rows, dtype=torch.int32, device=device).contiguous()
+    return table, len(rows), first
+
+
+def transpose_weights_batched(w_flat: torch.Tensor, wt_flat: torch.Tensor, table: torch.Tensor, n: int, blocks: int) -> None:
+    """Every ``[Co, T, Ci] -> [Ci, T, Co]`` copy of the flat weight mirror in one launch."""
+    if w_flat.dtype != torch.bfloat16 or wt_flat.dtype != torch.bfloat16 or w_flat.numel() != wt_flat.numel():
+        raise TypeError("transpose_weights_batched: expected two bf16 flat buffers of one size")
+    _check(_lib.pdt_transpose_w_batched(_p(w_flat), _p(wt_flat), _p(table), n, blocks, _stream()),
+           "pdt_transpose_w_batched")
 
 
 # --------------------------------------------------------------------------- batch norm

@@ -64,8 +64,13 @@ class XgmiAllReduce:
             ok = lib.pdt_car_ipc_handle(handle, mine) == 0
         # one exchange carries the verdict so far, the host name and the handle
         info = [None] * world
-        dist.all_gather_object(info, (bool(ok), socket.gethostname(), bytes(mine.raw)), group=group)
+        my_dev = device.index if device.index is not None else torch.cuda.current_device()
+        dist.all_gather_object(info, (bool(ok), socket.gethostname(), bytes(mine.raw), my_dev), group=group)
         ok = all(i[0] for i in info) and len({i[1] for i in info}) == 1
+        if ok:       # every peer GPU must be directly addressable from this one (xGMI / PCIe P2P)
+            for i in info:
+                if i[3] != my_dev and not torch.cuda.can_device_access_peer(my_dev, i[3]):
+                    ok = False
         if ok and world > 1:
             blob = b"".join(i[2] for i in info)
             ok = lib.pdt_car_open(handle, ctypes.c_char_p(blob)) == 0

@@ -198,6 +198,22 @@ def test_fused_finalize_from_conv_accumulator(hip, device, Ci, Co, H):
     assert torch.equal(y, y2) and torch.allclose(hip.stats_to_moments(mom), mom_ref, rtol=2e-3, atol=2e-4)
 
 
+def test_batched_weight_transpose(hip, device):
+    shapes = [(64, 9, 64), (256, 1, 64), (128, 9, 128), (2048, 1, 512), (24, 1, 40)]
+    offs, total = [], 0
+    for co, t, ci in shapes:
+        offs.append(total)
+        total += (co * t * ci + 127) // 128 * 128
+    flat = rnd(total, device=device)
+    wt = torch.zeros_like(flat)
+    table = hip.make_transpose_table([(o, co, t, ci) for o, (co, t, ci) in zip(offs, shapes)], device)
+    hip.transpose_weights_batched(flat, wt, *table)
+    for o, (co, t, ci) in zip(offs, shapes):
+        n = co * t * ci
+        ref_t = flat[o:o + n].view(co, t, ci).permute(2, 1, 0).contiguous().view(-1)
+        assert torch.equal(wt[o:o + n], ref_t)
+
+
 @pytest.mark.parametrize("B,H,C", [(2, 112, 64), (3, 30, 64), (1, 8, 128)])
 def test_pooling(hip, device, B, H, C):
     torch.manual_seed(B + H)
