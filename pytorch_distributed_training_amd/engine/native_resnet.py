@@ -375,8 +375,8 @@ class NativeResNet:
         return self._eval_affine[u.bn]
 
     # ------------------------------------------------------------------ forward
-    def _unit_forward(self, u: ConvBNSpec, x: torch.Tensor, residual: Optional[torch.Tensor], relu: bool,
-                      train: bool) -> torch.Tensor:
+    def _unit_conv_bn(self, u: ConvBNSpec, x: torch.Tensor, train: bool):
+        """conv + BatchNorm statistics/finalize of one unit: ``(y, scale, shift)``, nothing applied yet."""
         ops = self.ops
         w = self.params.compute(f"{u.conv}.weight")
         kw = {"defer_stats": True} if (train and self._fused_stats) else {}
@@ -386,20 +386,32 @@ class NativeResNet:
             ctx.x_in, ctx.y = x, y
             self._bn_train(u, ctx, moments, y.numel() // y.shape[-1])
             self._ctx[u.bn] = ctx
-            scale, shift = ctx.scale, ctx.shift
-        else:
-            scale, shift = self._affine_eval(u)
-        return ops.bn_apply(y, scale, shift, residual, relu)
+            return y, ctx.scale, ctx.shift
+        scale, shift = self._affine_eval(u)
+        return y, scale, shift
+
+    def _unit_forward(self, u: ConvBNSpec, x: torch.Tensor, residual: Optional[torch.Tensor], relu: bool,
+                      train: bool) -> torch.Tensor:
+        y, scale, shift = self._unit_conv_bn(u, x, train)
+        return self.ops.bn_apply(y, scale, shift, residual, relu)
 
     def _block_forward(self, b: BlockSpec, x: torch.Tensor, train: bool) -> torch.Tensor:
+        ops = self.ops
+        shortcut = None                    # (y, scale, shift) of a projection shortcut, applied in the tail
         identity = x
         if b.downsample is not None:
-            identity = self._unit_forward(b.downsample, x, None, False, train)
+            shortcut = self._unit_conv_bn(b.downsample, x, train)
+            if not hasattr(ops, "bn_apply2"):
+                identity = ops.bn_apply(*shortcut, None, False)
+                shortcut = None
         out = x
         last = len(b.units) - 1
         for i, u in enumerate(b.units):
             if i < last:
                 out = self._unit_forward(u, out, None, True, train)
+            elif shortcut is not None:
+                y, scale, shift = self._unit_conv_bn(u, out, train)
+                out = ops.bn_apply2(y, scale, shift, *shortcut, True)
             else:
                 out = self._unit_forward(u, out, identity, True, train)
         return out

@@ -105,6 +105,47 @@ PDT_API int pdt_bn_apply(const void* y, const float* scale, const float* shift, 
     return pdt_launch_status();
 }
 
+// Block tail with a projection shortcut: out = relu(y*scale + shift + y2*scale2 + shift2).  The
+// shortcut's normalised tensor is never written: its BatchNorm is applied here, on the fly.
+__global__ __launch_bounds__(256) void bn_apply2_kernel(const bf16* __restrict__ y, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         const bf16* __restrict__ y2, const float* __restrict__ scale2,
+                                                         const float* __restrict__ shift2, bf16* __restrict__ out,
+                                                         long long nvec, int cvec, int relu) {
+    long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvec) return;
+    int c0 = (int)(i % cvec) * 8;
+    float sc[8], sh[8], sc2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = scale[c0 + k];
+        sc2[k] = scale2[c0 + k];
+        sh[k] = shift[c0 + k] + shift2[c0 + k];
+    }
+    for (; i < nvec; i += stride) {
+        bf16x8 v = ld_bf16x8(y + i * 8);
+        bf16x8 r = ld_bf16x8(y2 + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float f = bf2f(v[k]) * sc[k] + bf2f(r[k]) * sc2[k] + sh[k];
+            if (relu) f = fmaxf(f, 0.0f);
+            o[k] = f2bf(f);
+        }
+        st_bf16x8(out + i * 8, o);
+    }
+}
+
+PDT_API int pdt_bn_apply2(const void* y, const float* scale, const float* shift, const void* y2, const float* scale2,
+                          const float* shift2, void* out, long long rows, int C, int relu, hipStream_t s) {
+    if (C % 8 != 0 || C / 8 > 256 || 256 % (C / 8) != 0) return -1;
+    long long nvec = rows * (C / 8);
+    hipLaunchKernelGGL(bn_apply2_kernel, dim3(ew_grid(nvec, 4)), dim3(256), 0, s, (const bf16*)y, scale, shift,
+                       (const bf16*)y2, scale2, shift2, (bf16*)out, nvec, C / 8, relu);
+    return pdt_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------
 // BatchNorm backward elementwise (fused ReLU mask):
 //   dy = g * mask ; dx = (dy - s0 - xhat*s1) * scale,  xhat = (y-mean)*invstd, [s0,s1] = sums*inv_count

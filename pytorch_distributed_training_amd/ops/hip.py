@@ -40,6 +40,7 @@ def _sig(fn_name: str, *argtypes) -> None:
 
 _sig("pdt_sgd_step", _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _i, _vp)
 _sig("pdt_bn_apply", _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp)
+_sig("pdt_bn_apply2", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp)
 _sig("pdt_bn_bwd_elemt", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _ll, _i, _i, _vp)
 _sig("pdt_input_pad", _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _vp)
 _sig("pdt_maxpool_fwd", _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
@@ -492,6 +493,21 @@ def bn_apply(y, scale, shift, residual, relu: bool):
     rc = _lib.pdt_bn_apply(_p(y), _p(scale), _p(shift), _p(residual), _p(out), y.numel() // C, C, int(bool(relu)),
                            _stream())
     _check(rc, "pdt_bn_apply")
+    return out
+
+
+def bn_apply2(y, scale, shift, y2, scale2, shift2, relu: bool):
+    """``relu(y*scale + shift + y2*scale2 + shift2)``: main path and projection shortcut of a block
+    normalised, added and activated in one pass."""
+    y = _bf16c(y, "bn_apply2 y")
+    y2 = _bf16c(y2, "bn_apply2 y2")
+    if y.shape != y2.shape:
+        raise ValueError("bn_apply2: the two tensors must have one shape")
+    C = y.shape[-1]
+    out = torch.empty_like(y)
+    rc = _lib.pdt_bn_apply2(_p(y), _p(scale), _p(shift), _p(y2), _p(scale2), _p(shift2), _p(out), y.numel() // C, C,
+                            int(bool(relu)), _stream())
+    _check(rc, "pdt_bn_apply2")
     return out
 
 

@@ -186,6 +186,15 @@ def _masked(g, y32, scale, shift, mask_src, mask_mode):
     return dy
 
 
+def bn_apply2(y, scale, shift, y2, scale2, shift2, relu: bool):
+    """``relu(y*scale + shift + y2*scale2 + shift2)`` -- a block's main path and its projection
+    shortcut normalised, added and activated in one pass (one rounding to the compute dtype)."""
+    out = y.float() * scale + shift + y2.float() * scale2 + shift2
+    if relu:
+        out = torch.relu(out)
+    return out.to(y.dtype)
+
+
 def bn_bwd_reduce(g, y, mean, invstd, scale, shift, mask_src, mask_mode: int,
                   dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``[2, C]``: local ``sum(dy)`` and ``sum(dy * xhat)`` with ``xhat = (y - mean) * invstd``.

@@ -158,6 +158,13 @@ def test_bn_family(hip, device, C, rows):
         out_ref = ref.bn_apply(y, sc_r, sh_r, r, relu)
         assert rel_err(out, out_ref) < 1e-2
 
+    if C <= 2048 and 256 % (C // 8) == 0:
+        y2 = rnd(1, rows, 1, C, device=device)
+        sc2, sh2 = torch.rand(C, device=device) + 0.5, torch.randn(C, device=device) * 0.1
+        for relu in (True, False):
+            out = hip.bn_apply2(y, sc_r, sh_r, y2, sc2, sh2, relu)
+            assert rel_err(out, ref.bn_apply2(y, sc_r, sh_r, y2, sc2, sh2, relu)) < 1e-2
+
     g = rnd(1, rows, 1, C, device=device)
     msrc = rnd(1, rows, 1, C, device=device)
     for mode, m in ((ref.MASK_NONE, None), (ref.MASK_TENSOR, msrc), (ref.MASK_RECOMPUTE, None)):
