@@ -12,8 +12,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$ROOT"
 PASSES=(
-  "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
-  "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
+  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES"
   "FETCH_SIZE"
   "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
 )
@@ -23,4 +22,4 @@ for counters in "${PASSES[@]}"; do
   # shellcheck disable=SC2086
   timeout -s KILL 120 rocprofv3 --kernel-trace --pmc $counters --output-format csv -d "$OUT/pass$i" -- python3 "$@"
 done
-find "$OUT" -name '*counter_collection.csv' -print
+python3 bench/pmc_summary.py "$OUT" | tee "$OUT/summary.txt"
