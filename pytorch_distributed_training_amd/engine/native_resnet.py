@@ -437,12 +437,10 @@ class NativeResNet:
                 scale, shift = ctx.scale, ctx.shift
             else:
                 scale, shift = self._affine_eval(stem)
-            a = ops.bn_apply(y, scale, shift, None, True)
-            x, idx = ops.maxpool_fwd(a)
+            x, idx = ops.bn_relu_maxpool_fwd(y, scale, shift)
             if train:
-                self._saved["stem_shape"] = tuple(a.shape)
+                self._saved["stem_shape"] = tuple(y.shape)
                 self._saved["pool_idx"] = idx
-            del a
             for b in self.spec.blocks:
                 x = self._block_forward(b, x, train)
             pooled = ops.avgpool_fwd(x)

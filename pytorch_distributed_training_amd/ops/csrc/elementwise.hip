@@ -261,9 +261,14 @@ PDT_API int pdt_input_pad(const void* src, void* dst, int B, int H, int W, int H
 // (at most 2x2) windows that selected it, so no atomics are needed.  Ties: first maximum in
 // (r, s) scan order wins, like ATen.
 // ------------------------------------------------------------------------------------------
+// AFFINE: the input is a raw conv output and relu(x*scale + shift), rounded to bf16 exactly as the
+// stand-alone BatchNorm-apply pass would store it, is pooled instead -- the stem's normalised
+// 112x112 activation is never written.
+template <bool AFFINE>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ out,
                                                            unsigned char* __restrict__ idx, int B, int H, int W,
-                                                           int C, int Ho, int Wo) {
+                                                           int C, int Ho, int Wo, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift) {
     int cvec = C / 8;
     long long total = (long long)B * Ho * Wo * cvec;
     long long stride = (long long)gridDim.x * blockDim.x;
@@ -273,10 +278,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16* __restrict
         int wo = (int)(t % Wo); t /= Wo;
         int ho = (int)(t % Ho);
         int b = (int)(t / Ho);
-        float best[8];
+        float best[8], sc[8], sh[8];
         unsigned char bi[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; bi[k] = 0; }
+        for (int k = 0; k < 8; ++k) {
+            best[k] = -INFINITY;
+            bi[k] = 0;
+            if (AFFINE) { sc[k] = scale[cv * 8 + k]; sh[k] = shift[cv * 8 + k]; }
+        }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             int h = ho * 2 - 1 + r;
@@ -289,6 +298,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16* __restrict
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     float f = bf2f(v[k]);
+                    if (AFFINE) f = bf2f(f2bf(fmaxf(f * sc[k] + sh[k], 0.0f)));
                     if (f > best[k]) { best[k] = f; bi[k] = (unsigned char)(r * 3 + s2); }
                 }
             }
@@ -347,8 +357,17 @@ PDT_API int pdt_maxpool_fwd(const void* x, void* out, void* idx, int B, int H, i
                             hipStream_t s) {
     if (C % 8) return -1;
     long long total = (long long)B * Ho * Wo * (C / 8);
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total, 1)), dim3(256), 0, s, (const bf16*)x, (bf16*)out,
-                       (unsigned char*)idx, B, H, W, C, Ho, Wo);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<false>, dim3(ew_grid(total, 1)), dim3(256), 0, s, (const bf16*)x, (bf16*)out,
+                       (unsigned char*)idx, B, H, W, C, Ho, Wo, nullptr, nullptr);
+    return pdt_launch_status();
+}
+
+PDT_API int pdt_bn_relu_maxpool_fwd(const void* y, const float* scale, const float* shift, void* out, void* idx, int B,
+                                    int H, int W, int C, int Ho, int Wo, hipStream_t s) {
+    if (C % 8) return -1;
+    long long total = (long long)B * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<true>, dim3(ew_grid(total, 1)), dim3(256), 0, s, (const bf16*)y, (bf16*)out,
+                       (unsigned char*)idx, B, H, W, C, Ho, Wo, scale, shift);
     return pdt_launch_status();
 }
 

@@ -44,6 +44,7 @@ _sig("pdt_bn_apply2", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp)
 _sig("pdt_bn_bwd_elemt", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _ll, _i, _i, _vp)
 _sig("pdt_input_pad", _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _vp)
 _sig("pdt_maxpool_fwd", _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
+_sig("pdt_bn_relu_maxpool_fwd", _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
 _sig("pdt_maxpool_bwd", _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
 _sig("pdt_avgpool_fwd", _vp, _vp, _i, _i, _i, _vp)
 _sig("pdt_avgpool_bwd", _vp, _vp, _vp, _i, _i, _i, _vp)
@@ -557,6 +558,18 @@ def maxpool_fwd(x):
     out = torch.empty(B, Ho, Wo, C, dtype=torch.bfloat16, device=x.device)
     idx = torch.empty(B, Ho, Wo, C, dtype=torch.uint8, device=x.device)
     _check(_lib.pdt_maxpool_fwd(_p(x), _p(out), _p(idx), B, H, W, C, Ho, Wo, _stream()), "pdt_maxpool_fwd")
+    return out, idx
+
+
+def bn_relu_maxpool_fwd(y, scale, shift):
+    """``maxpool3x3s2(relu(y*scale + shift))`` without materialising the normalised tensor."""
+    y = _bf16c(y, "bn_relu_maxpool_fwd")
+    B, H, W, C = y.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    out = torch.empty(B, Ho, Wo, C, dtype=torch.bfloat16, device=y.device)
+    idx = torch.empty(B, Ho, Wo, C, dtype=torch.uint8, device=y.device)
+    rc = _lib.pdt_bn_relu_maxpool_fwd(_p(y), _p(scale), _p(shift), _p(out), _p(idx), B, H, W, C, Ho, Wo, _stream())
+    _check(rc, "pdt_bn_relu_maxpool_fwd")
     return out, idx
 
 

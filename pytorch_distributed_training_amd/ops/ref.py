@@ -235,6 +235,11 @@ def maxpool_fwd(x: torch.Tensor):
     return _nhwc(out).to(x.dtype), idx
 
 
+def bn_relu_maxpool_fwd(y, scale, shift):
+    """``maxpool3x3s2(relu(y*scale + shift))``: the stem's BatchNorm-apply and pooling in one op."""
+    return maxpool_fwd(bn_apply(y, scale, shift, None, True))
+
+
 def maxpool_bwd(dout: torch.Tensor, idx: torch.Tensor, in_shape) -> torch.Tensor:
     B, H, W, C = in_shape
     # Overlapping 3x3/s2 windows can select the same input element twice and the gradient

@@ -232,6 +232,11 @@ def test_pooling(hip, device, B, H, C):
     dx = hip.maxpool_bwd(dout, idx, tuple(x.shape))
     dx_ref = ref.maxpool_bwd(dout, idx_ref, tuple(x.shape))
     assert rel_err(dx, dx_ref) < 1e-2
+    raw = rnd(B, H, H, C, device=device)
+    sc, sh = torch.rand(C, device=device) + 0.5, torch.randn(C, device=device) * 0.3
+    fo, fi = hip.bn_relu_maxpool_fwd(raw, sc, sh)
+    ro, ri = hip.maxpool_fwd(hip.bn_apply(raw, sc, sh, None, True))
+    assert torch.equal(fo, ro) and torch.equal(fi, ri)
     p = hip.avgpool_fwd(x)
     assert rel_err(p, ref.avgpool_fwd(x)) < 1e-2
     dp = rnd(B, C, device=device)
