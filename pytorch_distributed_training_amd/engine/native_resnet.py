@@ -144,6 +144,10 @@ class NativeResNet:
         # does fold + rank exchange + finalize (needs the in-kernel exchange when SyncBN is on).
         self._fused_stats = bool(getattr(ops, "fused_finalize", False)) and self.device.type == "cuda" \
             and (not self.sync_bn or self._xgmi is not None) and os.environ.get("PDT_FUSED_STATS", "1") == "1"
+        # BatchNorm-backward reductions accumulated by the data-gradient epilogue that produces
+        # the incoming gradient (saves the reduction pass over g and y).
+        self._fused_bwd_stats = bool(getattr(ops, "fused_bwd_stats", False)) and self.device.type == "cuda" \
+            and os.environ.get("PDT_FUSED_BWD_STATS", "1") == "1"
         # Step replay (see .graphs): the second step of a batch signature is recorded, later ones
         # replay the record.  "list": a command list of the backend's own launches (default);
         # "graph": HIP graphs separated by host actions.  PDT_HIP_GRAPHS: 0 = off, 1 = on,
@@ -321,16 +325,20 @@ class NativeResNet:
             ctx.scale, ctx.shift, ctx.mean, ctx.invstd = ops.bn_finalize(moments, inv_world, *args)
         ctx.count = count
 
-    def _bn_backward(self, u: ConvBNSpec, ctx: _UnitCtx, g: torch.Tensor, mask_src, mask_mode: int) -> torch.Tensor:
-        """Gradient w.r.t. the raw conv output; accumulates dgamma / dbeta into the flat buffer."""
+    def _bn_backward(self, u: ConvBNSpec, ctx: _UnitCtx, g: torch.Tensor, mask_src, mask_mode: int,
+                     prereduced: bool = False) -> torch.Tensor:
+        """Gradient w.r.t. the raw conv output; accumulates dgamma / dbeta into the flat buffer.
+        ``prereduced``: the data-gradient kernel that produced ``g`` already accumulated this
+        layer's sums (see :meth:`_bstats`), the reduction pass over ``g`` and ``y`` is skipped."""
         P, ops = self.params, self.ops
+        kw = {"prereduced": True} if prereduced else {}
         if self.sync_bn and self._xgmi is not None and self._fused_stats:
             sums = ops.bn_bwd_reduce(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, mask_src, mask_mode,
-                                     P.grad(f"{u.bn}.weight"), P.grad(f"{u.bn}.bias"), comm=self._xgmi)
+                                     P.grad(f"{u.bn}.weight"), P.grad(f"{u.bn}.bias"), comm=self._xgmi, **kw)
             return ops.bn_bwd_elemt(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, sums, 1.0 / ctx.count,
                                     mask_src, mask_mode)
         sums = ops.bn_bwd_reduce(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, mask_src, mask_mode,
-                                 P.grad(f"{u.bn}.weight"), P.grad(f"{u.bn}.bias"))
+                                 P.grad(f"{u.bn}.weight"), P.grad(f"{u.bn}.bias"), **kw)
         if self.sync_bn:
             # The all-reduce sits on the critical path (dgrad needs its result).  With
             # ``syncbn_overlap`` the weight gradient of the unit processed just before, which is
@@ -487,10 +495,23 @@ class NativeResNet:
         if red.completes_bucket(end_offset):        # otherwise nothing would be launched
             self._host(lambda: red.mark_ready(end_offset))
 
-    def _block_backward(self, b: BlockSpec, g: torch.Tensor) -> torch.Tensor:
+    def _bstats(self, u: Optional[ConvBNSpec], mask_mode: int):
+        """``bwd_stats`` argument for the data-gradient kernel whose result feeds ``u``'s BatchNorm
+        backward, or None when the backend cannot fuse that reduction."""
+        if u is None or not self._fused_bwd_stats:
+            return None
+        ctx = self._ctx[u.bn]
+        return {"bwd_stats": (ctx.y, ctx.mean, ctx.scale, ctx.shift, mask_mode)}
+
+    def _block_backward(self, b: BlockSpec, g: torch.Tensor, g_prereduced: bool = False,
+                        prev_last: Optional[ConvBNSpec] = None) -> torch.Tensor:
         """``g``: gradient w.r.t. the block's pre-ReLU sum, i.e. ALREADY multiplied by the mask of
         the block's output ReLU (the producer of ``g`` fuses that).  Returns the gradient w.r.t.
-        the block input, likewise already masked by the input tensor's own ReLU."""
+        the block input, likewise already masked by the input tensor's own ReLU.
+
+        ``g_prereduced``: the kernel that produced ``g`` also accumulated the backward sums of this
+        block's last BatchNorm.  ``prev_last``: the last unit of the block that produced this
+        block's input -- the final data-gradient kernel here does the same for it."""
         P, ops, red = self.params, self.ops, self.reducer
         last = len(b.units) - 1
         x_block = self._ctx[b.units[0].bn].x_in
@@ -500,14 +521,15 @@ class NativeResNet:
             u = b.units[i]
             ctx = self._ctx.pop(u.bn)
             if i == last:
-                dy = self._bn_backward(u, ctx, cur, None, MASK_NONE)
+                dy = self._bn_backward(u, ctx, cur, None, MASK_NONE, prereduced=g_prereduced)
             else:
-                dy = self._bn_backward(u, ctx, cur, None, MASK_RECOMPUTE)
+                dy = self._bn_backward(u, ctx, cur, None, MASK_RECOMPUTE, prereduced=self._fused_bwd_stats)
             key = f"{u.conv}.weight"
             self._wgrad(self._conv_wgrad_fn(u, ctx.x_in, dy))
             if i > 0:
                 cur = ops.conv_dgrad(dy, P.compute(key), self._wt_view(key), tuple(ctx.x_in.shape),
-                                     u.ksize, u.ksize, u.stride, u.pad)
+                                     u.ksize, u.ksize, u.stride, u.pad,
+                                     **(self._bstats(b.units[i - 1], MASK_RECOMPUTE) or {}))
             else:
                 dy_first = dy
         u0 = b.units[0]
@@ -525,7 +547,8 @@ class NativeResNet:
         # x_block is a post-ReLU tensor (previous block output, or the max-pooled stem activation,
         # where a zero means the whole pooling window was zero): apply its ReLU backward here.
         return ops.conv_dgrad(dy_first, P.compute(key0), self._wt_view(key0), tuple(x_block.shape),
-                              u0.ksize, u0.ksize, u0.stride, u0.pad, addend=other, relu_mask=x_block)
+                              u0.ksize, u0.ksize, u0.stride, u0.pad, addend=other, relu_mask=x_block,
+                              **(self._bstats(prev_last, MASK_NONE) or {}))
 
     def backward(self, dlogits: torch.Tensor) -> None:
         """Back-propagate ``dlogits``; gradients accumulate into the flat gradient buffer."""
@@ -539,8 +562,12 @@ class NativeResNet:
             self._mark_ready(P.end_offset("fc.bias"))
             H, W = self._saved.pop("final_hw")
             g = ops.avgpool_bwd(dpooled, H, W, relu_mask=self._saved.pop("final_out"))
-            for b in reversed(self.spec.blocks):
-                g = self._block_backward(b, g)
+            blocks = self.spec.blocks
+            pre = False
+            for j in range(len(blocks) - 1, -1, -1):
+                prev_last = blocks[j - 1].units[-1] if j > 0 else None
+                g = self._block_backward(blocks[j], g, pre, prev_last)
+                pre = prev_last is not None and self._fused_bwd_stats
             stem = self.spec.stem
             da = ops.maxpool_bwd(g, self._saved.pop("pool_idx"), self._saved.pop("stem_shape"))
             ctx = self._ctx.pop(stem.bn)

@@ -49,6 +49,14 @@ struct IgemmParams {
     const float* bias;
     float* stat_acc;
     const float* stat_shift;
+    // BatchNorm-BACKWARD sums of the layer that consumes this (data-gradient) output g: with
+    // bstat_y (that layer's raw conv output, same shape as the output here) the statistics slot
+    // accumulates [sum(dy), sum(dy * (y - mean))] instead of the forward moments, dy = g, or
+    // g * [y*scale + shift > 0] when bstat_scale is given (the layer's own ReLU, recomputed).
+    const bf16* bstat_y;
+    const float* bstat_mean;
+    const float* bstat_scale;
+    const float* bstat_shift;
     long long M;
     unsigned in_bytes, wgt_bytes;      // sizes of the input / weight tensors (buffer descriptors)
     int Hi, Wi, pix_stride, Ci;
@@ -74,7 +82,7 @@ __device__ __forceinline__ int swz_chunk(int row, int chunk) {
     return chunk ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3);   // BK == 32
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, bool BSTAT>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     constexpr int CH = BK / 8;            // 16-byte chunks per LDS row
     constexpr int RPP = 256 / CH;         // rows covered by one pass of the 256 threads
@@ -220,13 +228,20 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 
     // BatchNorm partial sums of the output loop's 8 channels (thread t: channel vector t % NV)
     const int cv = tid % NV;
-    float sh[8], s0[8], s1[8];
+    // BSTAT is a template parameter so the plain instantiations do not carry its registers
+    constexpr bool bwd_stats = BSTAT;
+    const bool bwd_mask = BSTAT && p.bstat_scale != nullptr;
+    float sh[8], s0[8], s1[8], msc[BSTAT ? 8 : 1], msh[BSTAT ? 8 : 1];
     int stat_n0 = -1;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         sh[k] = 0.f;
         s0[k] = 0.f;
         s1[k] = 0.f;
+        if (BSTAT) {
+            msc[k] = 0.f;
+            msh[k] = 1.f;
+        }
     }
 
     int v = blockIdx.x;                       // the launcher guarantees gridDim.x <= nwg
@@ -309,8 +324,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
         const int n = n0 + cv * 8;
         if (want_stats && stat_n0 != n0) {       // accumulators are empty whenever n0 changes
             stat_n0 = n0;
+            const float* center = bwd_stats ? p.bstat_mean : p.stat_shift;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) sh[k] = (p.stat_shift && n + k < p.N) ? p.stat_shift[n + k] : 0.0f;
+            for (int k = 0; k < 8; ++k) {
+                const bool in = n + k < p.N;
+                sh[k] = (center && in) ? center[n + k] : 0.0f;
+                if (BSTAT) {
+                    if (bwd_mask) {
+                        msc[k] = in ? p.bstat_scale[n + k] : 0.0f;
+                        msh[k] = in ? p.bstat_shift[n + k] : 1.0f;
+                    }
+                }
+            }
         }
         if (n < p.ldo) {                         // ldo is a multiple of 8 (checked by the launcher)
             for (int row = tid / NV; row < rows_valid; row += TR) {
@@ -332,13 +357,26 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) ov[k] = f2bf(bf2f(ov[k]) + bf2f(a[k]));
                 }
+                bf16x8 yv;
+                if (bwd_stats) yv = ld_bf16x8(p.bstat_y + o);
                 if (p.mask) {
                     bf16x8 mk = ld_bf16x8(p.mask + o);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) ov[k] = bf2f(mk[k]) > 0.0f ? ov[k] : f2bf(0.0f);
                 }
                 st_bf16x8(p.out + o, ov);
-                if (want_stats) {
+                if (bwd_stats) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float yy = bf2f(yv[k]);
+                        float dy = bf2f(ov[k]);
+                        if (BSTAT) {
+                            if (bwd_mask) dy = (yy * msc[k] + msh[k]) > 0.0f ? dy : 0.0f;
+                        }
+                        s0[k] += dy;
+                        s1[k] += dy * (yy - sh[k]);
+                    }
+                } else if (want_stats) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         float d = bf2f(ov[k]) - sh[k];
@@ -382,39 +420,46 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 }
 
 // Resident workgroups of one instantiation on the whole chip (queried once, then cached).
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, bool BSTAT>
 static int resident_blocks() {
     static int cached = 0;
     if (cached > 0) return cached;
     int per_cu = 0, dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 512;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, igemm_kernel<BM, BN, BK, WM, WN>, 256, 0) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, igemm_kernel<BM, BN, BK, WM, WN, BSTAT>, 256, 0) != hipSuccess ||
         per_cu <= 0)
         per_cu = 2;
     cached = per_cu * cus;
     return cached;
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
-static int launch_igemm(const IgemmParams& p, hipStream_t s) {
+template <int BM, int BN, int BK, int WM, int WN, bool BSTAT>
+static int launch_igemm_t(const IgemmParams& p, hipStream_t s) {
     int n_tiles_n = (p.N + BN - 1) / BN;
     long long n_tiles_m = (p.M + BM - 1) / BM;
     long long nwg = n_tiles_m * n_tiles_n;
     if (nwg <= 0 || nwg > 0x7fffffffLL) return -2;
-    long long grid = resident_blocks<BM, BN, BK, WM, WN>();
+    long long grid = resident_blocks<BM, BN, BK, WM, WN, BSTAT>();
     if (grid > nwg) grid = nwg;
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WM, WN>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WM, WN, BSTAT>), dim3((unsigned)grid), dim3(256), 0, s, p);
     return pdt_launch_status();
 }
 
+template <int BM, int BN, int BK, int WM, int WN>
+static int launch_igemm(const IgemmParams& p, hipStream_t s) {
+    return p.bstat_y ? launch_igemm_t<BM, BN, BK, WM, WN, true>(p, s) : launch_igemm_t<BM, BN, BK, WM, WN, false>(p, s);
+}
+
 // tile: 0 = auto, 1 = 128x128x64, 2 = 128x64x64, 3 = 64x64x64, 4 = 128x64x32 (stem), 5 = 64x128x64
-PDT_API int pdt_conv_igemm(const void* in, const void* wgt, void* out, const void* addend, const void* mask,
-                           const float* bias, float* stat_acc, const float* stat_shift, long long M, int Hi, int Wi,
-                           int pix_stride, int Ci, int Hg, int Wg, int IS, int Ho, int Wo, int OS, int oy0, int ox0,
-                           int N, int ldo, int wrow, int T, const signed char* offy, const signed char* offx,
-                           const unsigned short* widx, int tile, hipStream_t s) {
+static int conv_igemm_impl(const void* in, const void* wgt, void* out, const void* addend, const void* mask,
+                           const float* bias, float* stat_acc, const float* stat_shift, const void* bstat_y,
+                           const float* bstat_mean, const float* bstat_scale, const float* bstat_shift, long long M,
+                           int Hi, int Wi, int pix_stride, int Ci, int Hg, int Wg, int IS, int Ho, int Wo, int OS,
+                           int oy0, int ox0, int N, int ldo, int wrow, int T, const signed char* offy,
+                           const signed char* offx, const unsigned short* widx, int tile, hipStream_t s) {
     if (T < 0 || T > MAX_TAPS) return -3;
+    if (bstat_y && (!stat_acc || !bstat_mean || (bstat_scale && !bstat_shift) || ldo != N)) return -8;
     if (M <= 0) return 0;
     if (M >= 0x7fffffffLL) return -2;
     if (ldo % 8 != 0 || pix_stride % 4 != 0) return -4;
@@ -422,6 +467,7 @@ PDT_API int pdt_conv_igemm(const void* in, const void* wgt, void* out, const voi
     p.in = (const bf16*)in; p.wgt = (const bf16*)wgt; p.out = (bf16*)out;
     p.addend = (const bf16*)addend; p.mask = (const bf16*)mask; p.bias = bias;
     p.stat_acc = stat_acc; p.stat_shift = stat_shift;
+    p.bstat_y = (const bf16*)bstat_y; p.bstat_mean = bstat_mean; p.bstat_scale = bstat_scale; p.bstat_shift = bstat_shift;
     p.M = M; p.Hi = Hi; p.Wi = Wi; p.pix_stride = pix_stride; p.Ci = Ci;
     {
         long long images = M / ((long long)Hg * Wg);
@@ -454,4 +500,27 @@ PDT_API int pdt_conv_igemm(const void* in, const void* wgt, void* out, const voi
         case 5: return launch_igemm<64, 128, 64, 1, 4>(p, s);
         default: return -6;
     }
+}
+
+PDT_API int pdt_conv_igemm(const void* in, const void* wgt, void* out, const void* addend, const void* mask,
+                           const float* bias, float* stat_acc, const float* stat_shift, long long M, int Hi, int Wi,
+                           int pix_stride, int Ci, int Hg, int Wg, int IS, int Ho, int Wo, int OS, int oy0, int ox0,
+                           int N, int ldo, int wrow, int T, const signed char* offy, const signed char* offx,
+                           const unsigned short* widx, int tile, hipStream_t s) {
+    return conv_igemm_impl(in, wgt, out, addend, mask, bias, stat_acc, stat_shift, nullptr, nullptr, nullptr, nullptr, M,
+                           Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, ldo, wrow, T, offy, offx, widx,
+                           tile, s);
+}
+
+// Data gradient whose epilogue also accumulates the BatchNorm-backward sums of the consuming layer
+// (see IgemmParams::bstat_y).
+PDT_API int pdt_conv_igemm_bstats(const void* in, const void* wgt, void* out, const void* addend, const void* mask,
+                                  float* stat_acc, const void* bstat_y, const float* bstat_mean,
+                                  const float* bstat_scale, const float* bstat_shift, long long M, int Hi, int Wi,
+                                  int pix_stride, int Ci, int Hg, int Wg, int IS, int Ho, int Wo, int OS, int oy0,
+                                  int ox0, int N, int ldo, int wrow, int T, const signed char* offy,
+                                  const signed char* offx, const unsigned short* widx, int tile, hipStream_t s) {
+    return conv_igemm_impl(in, wgt, out, addend, mask, nullptr, stat_acc, nullptr, bstat_y, bstat_mean, bstat_scale,
+                           bstat_shift, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, ldo, wrow, T, offy,
+                           offx, widx, tile, s);
 }

@@ -71,6 +71,8 @@ _sig("pdt_car_query", _vp, _vp)
 _sig("pdt_car_destroy", _vp)
 _sig("pdt_conv_igemm", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
      _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp)
+_sig("pdt_conv_igemm_bstats", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+     _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp)
 _sig("pdt_conv_wgrad", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp)
 
 
@@ -234,7 +236,14 @@ def _stem_taps() -> _Taps:
 
 
 def _igemm(inp, wgt, out, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, ldo, wrow, taps: _Taps,
-           addend=None, mask=None, bias=None, stat_acc=None, stat_shift=None, tile: int = 0) -> None:
+           addend=None, mask=None, bias=None, stat_acc=None, stat_shift=None, tile: int = 0, bstat=None) -> None:
+    if bstat is not None:        # (acc, y, mean, scale-or-None, shift-or-None): BN-backward sums of the consumer
+        acc, by, bmean, bscale, bshift = bstat
+        rc = _lib.pdt_conv_igemm_bstats(_p(inp), _p(wgt), _p(out), _p(addend), _p(mask), _p(acc), _p(by), _p(bmean),
+                                        _p(bscale), _p(bshift), M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0,
+                                        ox0, N, ldo, wrow, taps.T, taps.offy, taps.offx, taps.widx, tile, _stream())
+        _check(rc, "pdt_conv_igemm_bstats")
+        return
     rc = _lib.pdt_conv_igemm(_p(inp), _p(wgt), _p(out), _p(addend), _p(mask), _p(bias), _p(stat_acc), _p(stat_shift),
                              M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, ldo, wrow, taps.T,
                              taps.offy, taps.offx, taps.widx, tile, _stream())
@@ -390,7 +399,12 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pa
 
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R: int, S: int, stride: int, pad: int,
-               addend: Optional[torch.Tensor] = None, relu_mask: Optional[torch.Tensor] = None, tile: int = 0):
+               addend: Optional[torch.Tensor] = None, relu_mask: Optional[torch.Tensor] = None, tile: int = 0,
+               bwd_stats=None):
+    """``bwd_stats = (y, mean, scale, shift, mask_mode)`` of the BatchNorm layer that consumes the
+    result ``g``: the epilogue also accumulates that layer's backward sums (what
+    :func:`bn_bwd_reduce` would compute from ``g`` and ``y`` in a pass of its own); pass
+    ``prereduced=True`` to :func:`bn_bwd_reduce` afterwards."""
     dy = _bf16c(dy, "conv_dgrad dy")
     if wt is None:
         raise ValueError("conv_dgrad: the hip backend needs the transposed weight copy wt[Cin,R,S,Cout]")
@@ -402,9 +416,18 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
     mask_src = None
     if relu_mask is not None:
         mask_src = _bf16c(relu_mask, "conv_dgrad relu_mask")
+    bstat = None
+    if bwd_stats is not None:
+        by, bmean, bscale, bshift, bmode = bwd_stats
+        by = _bf16c(by, "conv_dgrad bwd_stats y")
+        if tuple(by.shape) != (B, Hi, Wi, Ci) or bmode not in (MASK_NONE, MASK_RECOMPUTE):
+            raise ValueError("conv_dgrad: bwd_stats tensor/mode does not match the gradient being produced")
+        recompute = bmode == MASK_RECOMPUTE
+        bstat = (_accumulator(dy.device, Ci, "bwd"), by, bmean, bscale if recompute else None,
+                 bshift if recompute else None)
     if stride == 1:
         _igemm(dy, wt, dx, B * Hi * Wi, Ho, Wo, Co, Co, Hi, Wi, 1, Hi, Wi, 1, 0, 0, Ci, Ci, R * S * Co,
-               _dgrad_taps(R, S, pad, 1, 0, 0), addend=addend, mask=mask_src, tile=tile)
+               _dgrad_taps(R, S, pad, 1, 0, 0), addend=addend, mask=mask_src, tile=tile, bstat=bstat)
         return dx
     for ph in range(stride):
         for pw in range(stride):
@@ -413,7 +436,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
             if Hg <= 0 or Wg <= 0:
                 continue
             _igemm(dy, wt, dx, B * Hg * Wg, Ho, Wo, Co, Co, Hg, Wg, 1, Hi, Wi, stride, ph, pw, Ci, Ci, R * S * Co,
-                   _dgrad_taps(R, S, pad, stride, ph, pw), addend=addend, mask=mask_src, tile=tile)
+                   _dgrad_taps(R, S, pad, stride, ph, pw), addend=addend, mask=mask_src, tile=tile, bstat=bstat)
     return dx
 
 
@@ -512,9 +535,15 @@ def bn_apply2(y, scale, shift, y2, scale2, shift2, relu: bool):
     return out
 
 
-def bn_bwd_reduce(g, y, mean, invstd, scale, shift, mask_src, mask_mode: int, dgamma=None, dbeta=None, comm=None):
+fused_bwd_stats = True       # conv_dgrad(bwd_stats=...) + bn_bwd_reduce(prereduced=True)
+
+
+def bn_bwd_reduce(g, y, mean, invstd, scale, shift, mask_src, mask_mode: int, dgamma=None, dbeta=None, comm=None,
+                  prereduced: bool = False):
     """``comm`` (an ``XgmiAllReduce``): the returned sums are already summed over its ranks (the
-    exchange runs inside the kernel that folds the accumulator replicas)."""
+    exchange runs inside the kernel that folds the accumulator replicas).  ``prereduced``: the
+    accumulator already holds this layer's sums (the data-gradient epilogue that produced ``g``
+    put them there), only the fold remains."""
     g = _bf16c(g, "bn_bwd_reduce g")
     y = _bf16c(y, "bn_bwd_reduce y")
     if mask_mode == MASK_TENSOR:
@@ -522,9 +551,10 @@ def bn_bwd_reduce(g, y, mean, invstd, scale, shift, mask_src, mask_mode: int, dg
     C = y.shape[-1]
     rows = y.numel() // C
     acc = _accumulator(y.device, C, "bwd")
-    rc = _lib.pdt_bn_bwd_reduce_accum(_p(g), _p(y), _p(mask_src) if mask_mode == MASK_TENSOR else None, _p(mean),
-                                      _p(scale), _p(shift), _p(acc), rows, C, mask_mode, _stream())
-    _check(rc, "pdt_bn_bwd_reduce_accum")
+    if not prereduced:
+        rc = _lib.pdt_bn_bwd_reduce_accum(_p(g), _p(y), _p(mask_src) if mask_mode == MASK_TENSOR else None, _p(mean),
+                                          _p(scale), _p(shift), _p(acc), rows, C, mask_mode, _stream())
+        _check(rc, "pdt_bn_bwd_reduce_accum")
     sums = torch.empty(2, C, dtype=torch.float32, device=y.device)
     if comm is not None and 2 * C <= 2 * FUSED_MAX_C:
         rc = _lib.pdt_bn_bwd_sums_fused(_comm_handle(comm), _p(acc), _p(invstd), _p(sums), _p(dgamma), _p(dbeta), C,

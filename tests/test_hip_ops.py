@@ -205,6 +205,34 @@ def test_fused_finalize_from_conv_accumulator(hip, device, Ci, Co, H):
     assert torch.equal(y, y2) and torch.allclose(hip.stats_to_moments(mom), mom_ref, rtol=2e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("Ci,Co,k,stride,pad,H", [(64, 256, 1, 1, 0, 14), (128, 128, 3, 2, 1, 16), (256, 64, 3, 1, 1, 9),
+                                                  (512, 1024, 1, 2, 0, 14)])
+@pytest.mark.parametrize("mode", ["none", "recompute"])
+def test_dgrad_epilogue_accumulates_bn_backward_sums(hip, device, Ci, Co, k, stride, pad, H, mode):
+    """conv_dgrad(bwd_stats=...) + bn_bwd_reduce(prereduced=True) == conv_dgrad + bn_bwd_reduce."""
+    torch.manual_seed(Ci + Co + k)
+    B = 3
+    Ho = (H + 2 * pad - k) // stride + 1
+    dy = rnd(B, Ho, Ho, Co, device=device)
+    w = rnd(Co, k, k, Ci, device=device, scale=0.05)
+    wt = torch.empty(Ci, k, k, Co, dtype=torch.bfloat16, device=device)
+    hip.transpose_weights(w, wt)
+    y = rnd(B, H, H, Ci, device=device)                       # raw conv output of the consuming BN layer
+    mean, istd = torch.randn(Ci, device=device) * 0.1, torch.rand(Ci, device=device) + 0.5
+    sc, sh = torch.rand(Ci, device=device) + 0.5, torch.randn(Ci, device=device) * 0.2
+    m = ref.MASK_NONE if mode == "none" else ref.MASK_RECOMPUTE
+    g_plain = hip.conv_dgrad(dy, w, wt, (B, H, H, Ci), k, k, stride, pad)
+    dg0, db0 = torch.zeros(Ci, device=device), torch.zeros(Ci, device=device)
+    sums_ref = hip.bn_bwd_reduce(g_plain, y, mean, istd, sc, sh, None, m, dg0, db0)
+    g_fused = hip.conv_dgrad(dy, w, wt, (B, H, H, Ci), k, k, stride, pad, bwd_stats=(y, mean, sc, sh, m))
+    dg1, db1 = torch.zeros(Ci, device=device), torch.zeros(Ci, device=device)
+    sums = hip.bn_bwd_reduce(g_fused, y, mean, istd, sc, sh, None, m, dg1, db1, prereduced=True)
+    assert torch.equal(g_plain, g_fused)
+    tol = 1e-3 * max(float(sums_ref.abs().max()), 1.0)
+    assert torch.allclose(sums, sums_ref, rtol=1e-3, atol=tol)
+    assert torch.allclose(dg1, dg0, rtol=1e-3, atol=tol) and torch.allclose(db1, db0, rtol=1e-3, atol=tol)
+
+
 def test_batched_weight_transpose(hip, device):
     shapes = [(64, 9, 64), (256, 1, 64), (128, 9, 128), (2048, 1, 512), (24, 1, 40)]
     offs, total = [], 0
