@@ -106,6 +106,10 @@ class TorchEngine:
         tr = cfg["training"]
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
+        if self.cuda:
+            # what upstream switches on right after seeding (train_distributed.py:54): let the
+            # convolution library autotune its algorithm per shape (MIOpen find mode on ROCm)
+            torch.backends.cudnn.benchmark = True
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         model = get_model(cfg["model"]["name"], cfg["dataset"]["n_classes"]).to(self.device)
         if self.cuda:
