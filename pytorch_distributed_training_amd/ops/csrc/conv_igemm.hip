@@ -201,24 +201,67 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     auto compute = [&](int buf) {
         const unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
         const unsigned char* Bs = As + A_BYTES;
+        if constexpr (MI < 4) {
+            // few pixel fragments per wave: nothing to pipeline, let the compiler schedule freely
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                bf16x8 af[MI], bfr[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    int row = wm * WTM + i * 16 + frow;
+                    af[i] = *reinterpret_cast<const bf16x8*>(As + row * RB + (swz_chunk<BK>(row, kk * 4 + fq) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    int row = wn * WTN + j * 16 + frow;
+                    bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * RB + (swz_chunk<BK>(row, kk * 4 + fq) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-            bf16x8 af[MI], bfr[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                int row = wm * WTM + i * 16 + frow;
-                af[i] = *reinterpret_cast<const bf16x8*>(As + row * RB + (swz_chunk<BK>(row, kk * 4 + fq) << 4));
-            }
+            // The weight fragments of this k-slice and the first pixel fragment are read up front;
+            // pixel fragment i+1 is requested BEFORE the MFMAs of fragment i are issued (two
+            // fragment registers alternate), so an LDS read has NI MFMAs to land behind instead of
+            // stalling the wave once per fragment.
+            bf16x8 af[2], bfr[NI];
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 int row = wn * WTN + j * 16 + frow;
                 bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * RB + (swz_chunk<BK>(row, kk * 4 + fq) << 4));
             }
+            {
+                int row = wm * WTM + frow;
+                af[0] = *reinterpret_cast<const bf16x8*>(As + row * RB + (swz_chunk<BK>(row, kk * 4 + fq) << 4));
+            }
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i) {
+                if (i + 1 < MI) {
+                    int row = wm * WTM + (i + 1) * 16 + frow;
+                    af[(i + 1) & 1] =
+                        *reinterpret_cast<const bf16x8*>(As + row * RB + (swz_chunk<BK>(row, kk * 4 + fq) << 4));
+                }
+                if (kk > 0 && i == 0) {
+                    // the region since the previous pin holds the last MFMAs of the previous k-slice
+                    // and this slice's first reads: alternate them instead of reading after the MFMAs
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep that read ahead of the MFMAs below
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i & 1], acc[i][j], 0, 0, 0);
+            }
         }
     };
 
