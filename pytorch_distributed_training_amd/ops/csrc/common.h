@@ -26,6 +26,11 @@ __device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
 
 __device__ __forceinline__ bf16x8 ld_bf16x8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
 __device__ __forceinline__ void st_bf16x8(bf16* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
+// Streaming load: the line is not wanted again soon (last use of a tensor in this pass), so it
+// should not displace what the next kernel is about to read from L2 / the Infinity Cache.
+__device__ __forceinline__ bf16x8 ld_stream_bf16x8(const bf16* p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
+}
 
 __device__ __forceinline__ bf16x8 zero_bf16x8() {
     bf16x8 z;

@@ -75,9 +75,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 8; ++k) { sc[k] = scale[c0 + k]; sh[k] = shift[c0 + k]; }
     for (; i < nvec; i += stride) {
-        bf16x8 v = ld_bf16x8(y + i * 8);
+        bf16x8 v = ld_stream_bf16x8(y + i * 8);      // not read again before backward
         bf16x8 r;
-        if (RES) r = ld_bf16x8(res + i * 8);
+        if (RES) r = ld_stream_bf16x8(res + i * 8);
         bf16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const bf16* __restrict__
         sh[k] = shift[c0 + k] + shift2[c0 + k];
     }
     for (; i < nvec; i += stride) {
-        bf16x8 v = ld_bf16x8(y + i * 8);
-        bf16x8 r = ld_bf16x8(y2 + i * 8);
+        bf16x8 v = ld_stream_bf16x8(y + i * 8);
+        bf16x8 r = ld_stream_bf16x8(y2 + i * 8);
         bf16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -175,8 +175,8 @@ __global__ __launch_bounds__(256) void bn_bwd_elemt_kernel(const bf16* __restric
         sh[k] = shift[c0 + k];
     }
     for (; i < nvec; i += stride) {
-        bf16x8 gv = ld_bf16x8(g + i * 8);
-        bf16x8 yv = ld_bf16x8(y + i * 8);
+        bf16x8 gv = ld_stream_bf16x8(g + i * 8);     // last use of g and y in this step
+        bf16x8 yv = ld_stream_bf16x8(y + i * 8);
         bf16x8 mv;
         if (MODE == MASK_TENSOR) mv = ld_bf16x8(msrc + i * 8);
         bf16x8 o;
