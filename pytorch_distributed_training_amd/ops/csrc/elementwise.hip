@@ -68,13 +68,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ 
                                                         const bf16* __restrict__ res, bf16* __restrict__ out,
                                                         long long nvec, int cvec) {
     long long stride = (long long)gridDim.x * blockDim.x;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nvec) return;
-    int c0 = (int)(i % cvec) * 8;
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nvec) return;
+    // Walk the tensor from its END: the conv kernel that produced y wrote it front to back, so the
+    // tail is what the memory-side cache still holds; and the front of `out`, written last here,
+    // is what the next conv reads first.
+    int c0 = (int)((nvec - 1 - t) % cvec) * 8;
     float sc[8], sh[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { sc[k] = scale[c0 + k]; sh[k] = shift[c0 + k]; }
-    for (; i < nvec; i += stride) {
+    for (; t < nvec; t += stride) {
+        const long long i = nvec - 1 - t;
         bf16x8 v = ld_stream_bf16x8(y + i * 8);      // not read again before backward
         bf16x8 r;
         if (RES) r = ld_stream_bf16x8(res + i * 8);
@@ -113,9 +117,9 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const bf16* __restrict__
                                                          const float* __restrict__ shift2, bf16* __restrict__ out,
                                                          long long nvec, int cvec, int relu) {
     long long stride = (long long)gridDim.x * blockDim.x;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nvec) return;
-    int c0 = (int)(i % cvec) * 8;
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nvec) return;
+    int c0 = (int)((nvec - 1 - t) % cvec) * 8;      // back to front, as in bn_apply
     float sc[8], sh[8], sc2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -123,7 +127,8 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const bf16* __restrict__
         sc2[k] = scale2[c0 + k];
         sh[k] = shift[c0 + k] + shift2[c0 + k];
     }
-    for (; i < nvec; i += stride) {
+    for (; t < nvec; t += stride) {
+        const long long i = nvec - 1 - t;
         bf16x8 v = ld_stream_bf16x8(y + i * 8);
         bf16x8 r = ld_stream_bf16x8(y2 + i * 8);
         bf16x8 o;
@@ -161,9 +166,11 @@ __global__ __launch_bounds__(256) void bn_bwd_elemt_kernel(const bf16* __restric
                                                             const float* __restrict__ sums, float inv_count,
                                                             bf16* __restrict__ dx, long long nvec, int cvec, int C) {
     long long stride = (long long)gridDim.x * blockDim.x;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nvec) return;
-    int c0 = (int)(i % cvec) * 8;
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nvec) return;
+    // back to front: g was just written front to back by a data-gradient kernel, and the front of
+    // dx, written last, is what the next data-/weight-gradient kernels read first
+    int c0 = (int)((nvec - 1 - t) % cvec) * 8;
     float A[8], Bc[8], Cc[8], sh[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -174,7 +181,8 @@ __global__ __launch_bounds__(256) void bn_bwd_elemt_kernel(const bf16* __restric
         Cc[k] = (mu * is * s1 - s0) * sc;
         sh[k] = shift[c0 + k];
     }
-    for (; i < nvec; i += stride) {
+    for (; t < nvec; t += stride) {
+        const long long i = nvec - 1 - t;
         bf16x8 gv = ld_stream_bf16x8(g + i * 8);     // last use of g and y in this step
         bf16x8 yv = ld_stream_bf16x8(y + i * 8);
         bf16x8 mv;
