@@ -19,7 +19,12 @@ is written out here as a static program for one GPU per process:
   BatchNorm backward passes read no mask tensor.  No autograd graph is recorded;
 * after each layer's gradients are final the bucketed reducer
   (:mod:`..parallel.reducer`) is told how far the flat gradient buffer is complete, so
-  RCCL all-reduces overlap the rest of backward on a side stream.
+  RCCL all-reduces overlap the rest of backward on a side stream;
+* on the GPU the weight-gradient kernels run on a second stream (they are off the critical
+  path), the SyncBN statistics travel through a one-kernel xGMI exchange fused into the
+  finalize kernels (:mod:`..parallel.xgmi_allreduce`) when it passed its self-test, and the
+  whole step is recorded once and replayed (:mod:`.graphs`): a command list of the backend's
+  own launches by default, HIP graphs on request.
 
 The ops come from an op backend (``ops.hip`` on MI355X, ``ops.ref`` on CPU), so the same
 program is exercised by the CPU/gloo tests and checked against the eager model
