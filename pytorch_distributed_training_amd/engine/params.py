@@ -136,11 +136,15 @@ class FlatParams:
         return out
 
 
-def make_buckets(params: FlatParams, cap_mb: float, first_mb: float) -> List[Tuple[int, int]]:
+def make_buckets(params: FlatParams, cap_mb: float, first_mb: float, tail_mb: float = 2.0) -> List[Tuple[int, int]]:
     """Split the flat gradient buffer into contiguous ``[start, end)`` element ranges.
 
     The first bucket (the gradients backward produces first) is small so communication
-    starts early; the rest are capped at ``cap_mb``.  Entries are never split.
+    starts early; the rest are capped at ``cap_mb``.  The LAST bucket cannot overlap anything
+    (it completes with the final weight gradient, its all-reduce is exposed), so it is cut down
+    to the final ``tail_mb``: in a ResNet the early layers, whose gradients come last, hold few
+    parameters, and what precedes them in a cap-sized last bucket was ready milliseconds
+    earlier.  Entries are never split.
     """
     cap = max(int(cap_mb * 2 ** 20 / 4), 1)
     first = max(int(first_mb * 2 ** 20 / 4), 1)
@@ -155,4 +159,16 @@ def make_buckets(params: FlatParams, cap_mb: float, first_mb: float) -> List[Tup
             limit = cap
     if start < params.total:
         buckets.append((start, params.total))
+    tail = int(tail_mb * 2 ** 20 / 4)
+    if tail > 0 and buckets and buckets[-1][1] - buckets[-1][0] > 2 * tail:
+        lo, hi = buckets[-1]
+        cut = None
+        for key in params.order:                    # first entry boundary inside the last `tail` elements
+            off = params.entries[key].offset
+            if lo < off and hi - off <= tail:
+                cut = off
+                break
+        if cut is not None:
+            buckets[-1] = (lo, cut)
+            buckets.append((cut, hi))
     return buckets
