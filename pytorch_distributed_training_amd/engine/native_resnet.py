@@ -149,6 +149,11 @@ class NativeResNet:
         # does fold + rank exchange + finalize (needs the in-kernel exchange when SyncBN is on).
         self._fused_stats = bool(getattr(ops, "fused_finalize", False)) and self.device.type == "cuda" \
             and (not self.sync_bn or self._xgmi is not None) and os.environ.get("PDT_FUSED_STATS", "1") == "1"
+        # Producer -> consumer pairs around activations larger than this run in batch slices (the
+        # MI355X Infinity Cache holds 256 MB; a slice plus what streams past it must fit).
+        self._slice_bytes = 0
+        if self.device.type == "cuda" and getattr(ops, "batch_chunks", False):
+            self._slice_bytes = int(float(os.environ.get("PDT_SLICE_MB", "224")) * 2 ** 20)
         # BatchNorm-backward reductions accumulated by the data-gradient epilogue that produces
         # the incoming gradient (saves the reduction pass over g and y).
         self._fused_bwd_stats = bool(getattr(ops, "fused_bwd_stats", False)) and self.device.type == "cuda" \
@@ -388,12 +393,18 @@ class NativeResNet:
         return self._eval_affine[u.bn]
 
     # ------------------------------------------------------------------ forward
-    def _unit_conv_bn(self, u: ConvBNSpec, x: torch.Tensor, train: bool):
-        """conv + BatchNorm statistics/finalize of one unit: ``(y, scale, shift)``, nothing applied yet."""
+    def _unit_conv_bn(self, u: ConvBNSpec, x: torch.Tensor, train: bool, pre=None):
+        """conv + BatchNorm statistics/finalize of one unit: ``(y, scale, shift)``, nothing applied yet.
+        ``pre = (y, stats)``: the convolution has already been run (in batch slices, see
+        :meth:`_apply_then_convs`)."""
         ops = self.ops
-        w = self.params.compute(f"{u.conv}.weight")
-        kw = {"defer_stats": True} if (train and self._fused_stats) else {}
-        y, moments = ops.conv_fprop(x, w, u.ksize, u.ksize, u.stride, u.pad, self.rm(u.bn) if train else None, **kw)
+        if pre is not None:
+            y, moments = pre
+        else:
+            w = self.params.compute(f"{u.conv}.weight")
+            kw = {"defer_stats": True} if (train and self._fused_stats) else {}
+            y, moments = ops.conv_fprop(x, w, u.ksize, u.ksize, u.stride, u.pad, self.rm(u.bn) if train else None,
+                                        **kw)
         if train:
             ctx = _UnitCtx()
             ctx.x_in, ctx.y = x, y
@@ -404,30 +415,98 @@ class NativeResNet:
         return y, scale, shift
 
     def _unit_forward(self, u: ConvBNSpec, x: torch.Tensor, residual: Optional[torch.Tensor], relu: bool,
-                      train: bool) -> torch.Tensor:
-        y, scale, shift = self._unit_conv_bn(u, x, train)
+                      train: bool, pre=None) -> torch.Tensor:
+        y, scale, shift = self._unit_conv_bn(u, x, train, pre)
         return self.ops.bn_apply(y, scale, shift, residual, relu)
 
-    def _block_forward(self, b: BlockSpec, x: torch.Tensor, train: bool) -> torch.Tensor:
+    # -- cache-sized batch slices ---------------------------------------------------------------
+    def _n_slices(self, t: torch.Tensor) -> int:
+        """Number of batch slices for a producer -> consumer pair around tensor ``t``: 1 unless the
+        tensor is larger than the memory-side cache, then the smallest divisor of the batch that
+        makes a slice fit."""
+        if self._slice_bytes <= 0:
+            return 1
+        nbytes = t.numel() * t.element_size()
+        if nbytes <= self._slice_bytes:
+            return 1
+        B = t.shape[0]
+        for n in range(2, 9):
+            if B % n == 0 and nbytes // n <= self._slice_bytes:
+                return n
+        return 1
+
+    def _apply_then_convs(self, tail, users: List[ConvBNSpec], train: bool):
+        """Block tail (BatchNorm apply + shortcut + ReLU) and the convolutions that read its result,
+        run slice by slice over the batch: a 400 MB activation written in full and then re-read in
+        full goes to HBM and back, a 200 MB slice is still in the Infinity Cache when the
+        convolution reads it.  BatchNorm statistics of the convolutions accumulate over the
+        slices in the usual accumulator.  Returns the block output and ``{bn: (y, stats)}``."""
         ops = self.ops
+        kind, y, scale, shift, extra = tail
+        n = self._n_slices(y)
+        B = y.shape[0]
+        step = B // n
+        out = torch.empty_like(y)
+        ys, stats = {}, {}
+        for c in range(n):
+            sl = slice(c * step, (c + 1) * step)
+            if kind == "apply2":
+                y2, sc2, sh2 = extra
+                ops.bn_apply2(y[sl], scale, shift, y2[sl], sc2, sh2, True, out=out[sl])
+            else:
+                ops.bn_apply(y[sl], scale, shift, extra[sl] if extra is not None else None, True, out=out[sl])
+            for k, u in enumerate(users):
+                w = self.params.compute(f"{u.conv}.weight")
+                Ho = (y.shape[1] + 2 * u.pad - u.ksize) // u.stride + 1
+                Wo = (y.shape[2] + 2 * u.pad - u.ksize) // u.stride + 1
+                if u.bn not in ys:
+                    ys[u.bn] = torch.empty(B, Ho, Wo, u.cout, dtype=y.dtype, device=y.device)
+                _, st = ops.conv_fprop(out[sl], w, u.ksize, u.ksize, u.stride, u.pad,
+                                       self.rm(u.bn) if train else None, defer_stats=train, out=ys[u.bn][sl],
+                                       acc_slot="stats" if k == 0 else f"stats{k}")
+                if st is not None:
+                    st.count = B * Ho * Wo          # the accumulator ends up holding every slice
+                    stats[u.bn] = st
+        return out, {bn: (ys[bn], stats.get(bn)) for bn in ys}
+
+    def _block_forward(self, b: BlockSpec, x, train: bool):
+        """``x``: the block input, or the previous block's un-applied tail (a tuple, see below) when
+        that tensor is worth slicing.  Returns this block's output the same way."""
+        ops = self.ops
+        pre = {}
+        if isinstance(x, tuple):
+            users = [b.units[0]] + ([b.downsample] if b.downsample is not None else [])
+            x, pre = self._apply_then_convs(x, users, train)
         shortcut = None                    # (y, scale, shift) of a projection shortcut, applied in the tail
         identity = x
         if b.downsample is not None:
-            shortcut = self._unit_conv_bn(b.downsample, x, train)
+            shortcut = self._unit_conv_bn(b.downsample, x, train, pre.get(b.downsample.bn))
             if not hasattr(ops, "bn_apply2"):
                 identity = ops.bn_apply(*shortcut, None, False)
                 shortcut = None
         out = x
         last = len(b.units) - 1
         for i, u in enumerate(b.units):
+            p = pre.get(u.bn) if i == 0 else None
             if i < last:
-                out = self._unit_forward(u, out, None, True, train)
-            elif shortcut is not None:
-                y, scale, shift = self._unit_conv_bn(u, out, train)
-                out = ops.bn_apply2(y, scale, shift, *shortcut, True)
-            else:
-                out = self._unit_forward(u, out, identity, True, train)
+                out = self._unit_forward(u, out, None, True, train, p)
+                continue
+            y, scale, shift = self._unit_conv_bn(u, out, train, p)
+            tail = ("apply2", y, scale, shift, shortcut) if shortcut is not None else \
+                ("apply", y, scale, shift, identity)
+            if self._can_slice(train) and self._n_slices(y) > 1 and b is not self.spec.blocks[-1]:
+                return tail                 # applied by the next block, slice by slice with its convs
+            return self._apply_tail(tail)
         return out
+
+    def _can_slice(self, train: bool) -> bool:
+        return self._slice_bytes > 0 and (self._fused_stats or not train)
+
+    def _apply_tail(self, tail) -> torch.Tensor:
+        kind, y, scale, shift, extra = tail
+        if kind == "apply2":
+            return self.ops.bn_apply2(y, scale, shift, *extra, True)
+        return self.ops.bn_apply(y, scale, shift, extra, True)
 
     def forward(self, img: torch.Tensor, train: Optional[bool] = None) -> torch.Tensor:
         """Logits ``[B, num_classes]`` for a loader batch (float NCHW or uint8 NHWC)."""
@@ -456,6 +535,8 @@ class NativeResNet:
                 self._saved["pool_idx"] = idx
             for b in self.spec.blocks:
                 x = self._block_forward(b, x, train)
+            if isinstance(x, tuple):
+                x = self._apply_tail(x)
             pooled = ops.avgpool_fwd(x)
             if train:
                 self._saved["final_hw"] = (x.shape[1], x.shape[2])

@@ -380,6 +380,15 @@ def stem_wgrad(x0: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) -> None:
     _check(_lib.pdt_stem_unpack_add(_p(scratch), _p(dw), Co, _stream()), "pdt_stem_unpack_add")
 
 
+
+def _out_like(out: Optional[torch.Tensor], shape, device, what: str) -> torch.Tensor:
+    """``out`` (a caller-provided bf16 destination, e.g. a batch slice of a larger tensor) or a new tensor."""
+    if out is None:
+        return torch.empty(*shape, dtype=torch.bfloat16, device=device)
+    if tuple(out.shape) != tuple(shape) or out.dtype != torch.bfloat16 or not out.is_contiguous() or not out.is_cuda:
+        raise ValueError(f"{what}: out must be a contiguous bf16 GPU tensor of shape {tuple(shape)}")
+    return out
+
 # Static per-shape tile selection (what upstream leaves to cudnn.benchmark autotuning): shapes on
 # which the 64x128 tile measured faster than the launcher's own choice at per-GPU batch 256
 # (bench/conv_layers.py --tile sweep).  Key: (op, Cin, Cout, k, stride, input H).  Only applied to
@@ -397,15 +406,18 @@ def _tile_hint(op: str, B: int, Ci: int, Co: int, k: int, stride: int, H: int) -
 
 # --------------------------------------------------------------------------- convolution
 def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pad: int,
-               stat_shift: Optional[torch.Tensor] = None, tile: int = 0, defer_stats: bool = False):
+               stat_shift: Optional[torch.Tensor] = None, tile: int = 0, defer_stats: bool = False,
+               out: Optional[torch.Tensor] = None, acc_slot: str = "stats"):
+    """``acc_slot``: which statistics accumulator to use -- two convolutions whose deferred
+    statistics are pending at the same time (interleaved batch slices) need distinct ones."""
     x = _bf16c(x, "conv_fprop x")
     w = _bf16c(w, "conv_fprop w")
     B, Hi, Wi, Ci = x.shape
     Co = w.shape[0]
     Ho, Wo = (Hi + 2 * pad - R) // stride + 1, (Wi + 2 * pad - S) // stride + 1
-    y = torch.empty(B, Ho, Wo, Co, dtype=torch.bfloat16, device=x.device)
+    y = _out_like(out, (B, Ho, Wo, Co), x.device, "conv_fprop")
     M = B * Ho * Wo
-    acc = _accumulator(x.device, Co, "stats") if stat_shift is not None else None
+    acc = _accumulator(x.device, Co, acc_slot) if stat_shift is not None else None
     if tile == 0 and R == S and Hi == Wi:
         tile = _tile_hint("fprop", B, Ci, Co, R, stride, Hi)
     _igemm(x, w, y, M, Hi, Wi, Ci, Ci, Ho, Wo, stride, Ho, Wo, 1, 0, 0, Co, Co, R * S * Ci, _fprop_taps(R, S, pad),
@@ -417,7 +429,7 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pa
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R: int, S: int, stride: int, pad: int,
                addend: Optional[torch.Tensor] = None, relu_mask: Optional[torch.Tensor] = None, tile: int = 0,
-               bwd_stats=None):
+               bwd_stats=None, out: Optional[torch.Tensor] = None):
     """``bwd_stats = (y, mean, scale, shift, mask_mode)`` of the BatchNorm layer that consumes the
     result ``g``: the epilogue also accumulates that layer's backward sums (what
     :func:`bn_bwd_reduce` would compute from ``g`` and ``y`` in a pass of its own); pass
@@ -427,7 +439,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
         raise ValueError("conv_dgrad: the hip backend needs the transposed weight copy wt[Cin,R,S,Cout]")
     B, Hi, Wi, Ci = in_shape
     _, Ho, Wo, Co = dy.shape
-    dx = torch.empty(B, Hi, Wi, Ci, dtype=torch.bfloat16, device=dy.device)
+    dx = _out_like(out, (B, Hi, Wi, Ci), dy.device, "conv_dgrad")
     if addend is not None:
         addend = _bf16c(addend, "conv_dgrad addend")
     mask_src = None
@@ -527,10 +539,10 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps: float):
     return out[0], out[1]
 
 
-def bn_apply(y, scale, shift, residual, relu: bool):
+def bn_apply(y, scale, shift, residual, relu: bool, out: Optional[torch.Tensor] = None):
     y = _bf16c(y, "bn_apply y")
     C = y.shape[-1]
-    out = torch.empty_like(y)
+    out = _out_like(out, y.shape, y.device, "bn_apply")
     if residual is not None:
         residual = _bf16c(residual, "bn_apply residual")
     rc = _lib.pdt_bn_apply(_p(y), _p(scale), _p(shift), _p(residual), _p(out), y.numel() // C, C, int(bool(relu)),
@@ -539,7 +551,7 @@ def bn_apply(y, scale, shift, residual, relu: bool):
     return out
 
 
-def bn_apply2(y, scale, shift, y2, scale2, shift2, relu: bool):
+def bn_apply2(y, scale, shift, y2, scale2, shift2, relu: bool, out: Optional[torch.Tensor] = None):
     """``relu(y*scale + shift + y2*scale2 + shift2)``: main path and projection shortcut of a block
     normalised, added and activated in one pass."""
     y = _bf16c(y, "bn_apply2 y")
@@ -547,13 +559,14 @@ def bn_apply2(y, scale, shift, y2, scale2, shift2, relu: bool):
     if y.shape != y2.shape:
         raise ValueError("bn_apply2: the two tensors must have one shape")
     C = y.shape[-1]
-    out = torch.empty_like(y)
+    out = _out_like(out, y.shape, y.device, "bn_apply2")
     rc = _lib.pdt_bn_apply2(_p(y), _p(scale), _p(shift), _p(y2), _p(scale2), _p(shift2), _p(out), y.numel() // C, C,
                             int(bool(relu)), _stream())
     _check(rc, "pdt_bn_apply2")
     return out
 
 
+batch_chunks = True          # ops take out= destinations, so a batch can be processed in cache-sized slices
 fused_bwd_stats = True       # conv_dgrad(bwd_stats=...) + bn_bwd_reduce(prereduced=True)
 
 
@@ -587,11 +600,12 @@ def bn_bwd_reduce(g, y, mean, invstd, scale, shift, mask_src, mask_mode: int, dg
     return sums
 
 
-def bn_bwd_elemt(g, y, mean, invstd, scale, shift, sums, inv_count: float, mask_src, mask_mode: int):
+def bn_bwd_elemt(g, y, mean, invstd, scale, shift, sums, inv_count: float, mask_src, mask_mode: int,
+                 out: Optional[torch.Tensor] = None):
     g = _bf16c(g, "bn_bwd_elemt g")
     y = _bf16c(y, "bn_bwd_elemt y")
     C = y.shape[-1]
-    dx = torch.empty_like(y)
+    dx = _out_like(out, y.shape, y.device, "bn_bwd_elemt")
     rc = _lib.pdt_bn_bwd_elemt(_p(g), _p(y), _p(mask_src) if mask_mode == MASK_TENSOR else None, _p(mean), _p(invstd),
                                _p(scale), _p(shift), _p(sums), inv_count, _p(dx), y.numel() // C, C, mask_mode,
                                _stream())

@@ -59,6 +59,29 @@ def test_hip_engine_matches_reference_engine(device, name, B, H):
     assert nerr(a.running_var, c.running_var) < 2.0 * nerr(b.running_var, c.running_var) + 1e-2
 
 
+@pytest.mark.parametrize("name", ["ResNet18", "ResNet50"])
+def test_batch_sliced_forward_matches_unsliced(device, name, monkeypatch):
+    """Forcing the cache-sized batch slicing of block-boundary passes (tiny threshold) changes launch
+    order only: loss and gradients stay within bf16 noise of the unsliced engine."""
+    from pytorch_distributed_training_amd.ops import hip
+    monkeypatch.setenv("PDT_SLICE_MB", "0")
+    a = _build(name, device, hip)
+    monkeypatch.setenv("PDT_SLICE_MB", "0.25")
+    b = _build(name, device, hip)
+    assert a._slice_bytes == 0 and b._slice_bytes > 0
+    c = _build_dtype(name, device, ref, torch.float32)
+    torch.manual_seed(5)
+    img = torch.randn(8, 3, 128, 128, device=device)
+    label = torch.randint(0, 1000, (8,), device=device)
+    la, lb, lc = (e.forward_backward(img, label).item() for e in (a, b, c))
+    assert b._n_slices(torch.empty(8, 32, 32, 64, device=device, dtype=torch.bfloat16)) > 1
+    cos = torch.nn.functional.cosine_similarity
+    ea = 1.0 - cos(a.params.g, c.params.g, dim=0).item()
+    eb = 1.0 - cos(b.params.g, c.params.g, dim=0).item()
+    assert abs(lb - lc) < 0.05 * max(1.0, abs(lc)), (la, lb, lc)
+    assert eb < 2.0 * ea + 5e-3, (ea, eb)
+
+
 def test_hip_training_reduces_loss(device):
     from pytorch_distributed_training_amd.ops import hip
     eng = _build("ResNet50", device, hip)
