@@ -21,7 +21,7 @@ name = "hip"
 needs_wt = True
 NREP = 16
 
-_LIB_PATH = _build.LIB
+_LIB_PATH = os.environ.get("PDT_HIP_LIB") or _build.LIB      # PDT_HIP_LIB: e.g. the host-sanitized debug build
 if not os.path.exists(_LIB_PATH):
     raise ImportError(
         f"{_LIB_PATH} is missing: build the gfx950 kernels first with "

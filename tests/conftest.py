@@ -13,6 +13,7 @@ torch.set_num_threads(max(1, min(4, os.cpu_count() or 1)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "multigpu: needs two or more GPUs on the node (also carries the gpu marker)")
     config.addinivalue_line("markers", "slow: long-running CPU test")
 
 
