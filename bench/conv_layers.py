@@ -58,6 +58,7 @@ def main() -> int:
     ap.add_argument("--target-blocks", type=int, default=0)
     ap.add_argument("--atomic-mb", type=int, default=0)
     ap.add_argument("--stats", type=int, default=1)
+    ap.add_argument("--blas", type=int, default=0, help="also time the plain library GEMM (1x1 stride-1 layers)")
     args = ap.parse_args()
     from pytorch_distributed_training_amd.ops import hip
 
@@ -101,8 +102,15 @@ def main() -> int:
                 ref = lambda: torch.nn.grad.conv2d_weight(xt, wtch.shape, dyt, stride, pad)
             t = timeit(fn)
             tm = timeit(ref, iters=5, warmup=2) if args.miopen else float("nan")
+            blas = ""
+            if args.blas and k == 1 and stride == 1:
+                x2, y2, w2 = x.view(-1, Ci), dy.view(-1, Co), w.view(Co, Ci)
+                gemm = {"fprop": lambda: torch.mm(x2, w2.t()), "dgrad": lambda: torch.mm(y2, w2),
+                        "wgrad": lambda: torch.mm(y2.t(), x2)}[op]
+                tb = timeit(gemm)
+                blas = f"  blas {tb:8.1f} us {flops / tb / 1e6:7.1f} TF/s  x{tb / t:5.2f}"
             print(f"{lid:5s} {op:6s} {t:9.1f} {flops / t / 1e6:7.1f} {ideal / 1e9:9.3f} {ideal / t / 1e6:6.2f} "
-                  f"{tm:10.1f} {tm / t:8.2f}", flush=True)
+                  f"{tm:10.1f} {tm / t:8.2f}{blas}", flush=True)
             rows.append((lid, op, count, t, flops / t / 1e6, ideal / 1e9, ideal / t / 1e6, tm))
             totals[op][0] += t * count
             totals[op][1] += tm * count
