@@ -235,8 +235,39 @@ def _stem_taps() -> _Taps:
     return _tap_cache[key]
 
 
+# The conv kernels address their gathered operand through a buffer descriptor with 32-bit byte
+# offsets (out-of-range taps read zeros for free), so one launch sees at most 2 GB of it; larger
+# batches (per-GPU batch > ~1200 on ResNet-50's first stage) go out as several launches over
+# batch ranges -- rows of different images are independent, statistics and weight gradients
+# accumulate across the launches.
+MAX_OPERAND_BYTES = 0x70000000
+
+
+def _batch_parts(B: int, nbytes: int):
+    n = -(-nbytes // MAX_OPERAND_BYTES)
+    if n <= 1 or B <= 1:
+        return None
+    step = -(-B // n)
+    return [(b, min(b + step, B)) for b in range(0, B, step)]
+
+
+def _part(t, b0: int, b1: int):
+    return None if t is None else t[b0:b1]
+
+
 def _igemm(inp, wgt, out, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, ldo, wrow, taps: _Taps,
            addend=None, mask=None, bias=None, stat_acc=None, stat_shift=None, tile: int = 0, bstat=None) -> None:
+    parts = _batch_parts(inp.shape[0], inp.numel() * inp.element_size())
+    if parts is not None:
+        B = inp.shape[0]
+        if out.shape[0] != B or M % B:
+            raise ValueError("conv: cannot split this launch over the batch")
+        for b0, b1 in parts:
+            sub = None if bstat is None else (bstat[0], bstat[1][b0:b1], *bstat[2:])
+            _igemm(inp[b0:b1], wgt, out[b0:b1], (M // B) * (b1 - b0), Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS,
+                   oy0, ox0, N, ldo, wrow, taps, addend=_part(addend, b0, b1), mask=_part(mask, b0, b1), bias=bias,
+                   stat_acc=stat_acc, stat_shift=stat_shift, tile=tile, bstat=sub)
+        return
     if bstat is not None:        # (acc, y, mean, scale-or-None, shift-or-None): BN-backward sums of the consumer
         acc, by, bmean, bscale, bshift = bstat
         rc = _lib.pdt_conv_igemm_bstats(_p(inp), _p(wgt), _p(out), _p(addend), _p(mask), _p(acc), _p(by), _p(bmean),
@@ -252,6 +283,15 @@ def _igemm(inp, wgt, out, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0
 
 def _wgrad(dy, inp, dw, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow, taps: _Taps, tile: int = 0,
            target_blocks: int = 0, atomic_budget_mb: int = 0) -> None:
+    parts = _batch_parts(inp.shape[0], max(inp.numel(), dy.numel()) * 2)
+    if parts is not None:
+        B = inp.shape[0]
+        if dy.shape[0] != B or M % B:
+            raise ValueError("conv_wgrad: cannot split this launch over the batch")
+        for b0, b1 in parts:
+            _wgrad(dy[b0:b1], inp[b0:b1], dw, (M // B) * (b1 - b0), Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow,
+                   taps, tile=tile, target_blocks=target_blocks, atomic_budget_mb=atomic_budget_mb)
+        return
     rc = _lib.pdt_conv_wgrad(_p(dy), _p(inp), _p(dw), M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow, taps.T,
                              taps.offy, taps.offx, taps.widx, tile, target_blocks, atomic_budget_mb, _stream())
     _check(rc, "pdt_conv_wgrad")

@@ -89,6 +89,42 @@ def test_conv_tiles(hip, device, tile):
     assert rel_err(y, y_ref) < 1.5e-2
 
 
+@pytest.mark.parametrize("k,stride,pad", [(1, 1, 0), (3, 1, 1), (3, 2, 1)])
+def test_conv_launches_split_over_the_batch(hip, device, monkeypatch, k, stride, pad):
+    """Operands beyond the 2 GB buffer-descriptor window go out as several launches over batch
+    ranges (threshold lowered here): same outputs, statistics and weight gradients."""
+    torch.manual_seed(k + stride)
+    B, H, Ci, Co = 7, 12, 64, 128
+    x = rnd(B, H, H, Ci, device=device)
+    w = rnd(Co, k, k, Ci, device=device, scale=(2.0 / (k * k * Ci)) ** 0.5)
+    wt = torch.empty(Ci, k, k, Co, dtype=torch.bfloat16, device=device)
+    hip.transpose_weights(w, wt)
+    shift = torch.zeros(Co, device=device)
+
+    def run():
+        y, mom = hip.conv_fprop(x, w, k, k, stride, pad, shift)
+        dy = (y.float() * 0.5 + 0.1).to(torch.bfloat16)
+        mean = torch.randn(Ci, device=device) * 0.1
+        dx = hip.conv_dgrad(dy, w, wt, tuple(x.shape), k, k, stride, pad, addend=x, relu_mask=x,
+                            bwd_stats=(x, mean, None, None, ref.MASK_NONE))
+        sums = hip.bn_bwd_reduce(dx, x, mean, torch.ones(Ci, device=device), None, None, None, ref.MASK_NONE,
+                                 prereduced=True)
+        dw = torch.zeros(Co, k, k, Ci, dtype=torch.float32, device=device)
+        hip.conv_wgrad(x, dy, k, k, stride, pad, dw)
+        return y, mom, dx, sums, dw
+
+    torch.manual_seed(1)
+    whole = run()
+    monkeypatch.setattr(hip, "MAX_OPERAND_BYTES", x[:2].numel() * 2)       # -> 4 launches of <= 2 images
+    assert len(hip._batch_parts(B, x.numel() * 2)) == 4
+    torch.manual_seed(1)
+    split = run()
+    assert torch.equal(whole[0], split[0]) and torch.equal(whole[2], split[2])
+    assert torch.allclose(whole[1], split[1], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(whole[3], split[3], rtol=1e-3, atol=1e-2)
+    assert rel_err(split[4], whole[4]) < 1e-4
+
+
 @pytest.mark.parametrize("tile", [1, 2, 4])
 def test_wgrad_tiles(hip, device, tile):
     torch.manual_seed(tile)
