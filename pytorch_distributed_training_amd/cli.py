@@ -1,9 +1,10 @@
 """Command-line entry point: ``python -m pytorch_distributed_training_amd.cli ...``.
 
 Accepts upstream's nine flags with the same names and defaults (reference
-``train_distributed.py:38-49``; example invocation in ``train.sh:6-14``) plus three
+``train_distributed.py:38-49``; example invocation in ``train.sh:6-14``) plus four
 additions: ``--set a.b=c`` config overrides, ``--nproc-per-node`` (process count when it
-should not be derived from the GPU count, e.g. CPU/gloo runs) and ``--ops-backend``.
+should not be derived from the GPU count, e.g. CPU/gloo runs), ``--ops-backend`` and
+``--eval-only`` (one validation pass over the checkpoint in ``training.resume``).
 
 Failure handling differs from upstream on purpose: upstream's handler removes the whole
 log directory on any exception (``shutil.rmtree(os.path.join(log_dir), "tf-board-logs")``,
@@ -44,6 +45,8 @@ def build_parser() -> argparse.ArgumentParser:
                    help="override a config key (repeatable)")
     p.add_argument("--nproc-per-node", type=int, default=None, help="processes per node (default: GPU count)")
     p.add_argument("--ops-backend", type=str, default="auto", choices=("auto", "hip", "ref"))
+    p.add_argument("--eval-only", action="store_true",
+                   help="evaluate the checkpoint named by training.resume on the validation split and exit")
     return p
 
 
@@ -61,7 +64,7 @@ def main(argv=None) -> int:
     logger = logger_listener.get_logger("Runner")
     status = 0
     try:
-        cfg = get_cfg(args.cfg_filepath, args.overrides)
+        cfg = get_cfg(args.cfg_filepath, args.overrides + (["runtime.eval_only=true"] if args.eval_only else []))
         logger.info("Starting distributed runner")
         launch(cfg, args.num_nodes, args.rank, args.dist_url, args.dist_backend, args.multiprocessing, args.seed,
                args.log_dir, args.file_name_cfg, logger_listener.queue, args.nproc_per_node, args.ops_backend,

@@ -87,6 +87,7 @@ _SCHEMA: Dict[str, Any] = {
         "deterministic": (bool, False),
         "hip_graphs": (bool, True),            # native engine on GPU: record the step once, then replay it
         "step_replay": (str, "list"),          # list (command list of stream launches) | graph (HIP graphs) | off
+        "eval_only": (bool, False),            # load training.resume (if any), run one validation pass, exit
     },
 }
 

@@ -19,6 +19,7 @@ fixed  the device is selected before anything touches it; the sampler's epoch ad
 """
 from __future__ import annotations
 
+import itertools
 import math
 import os
 import time
@@ -226,12 +227,11 @@ class Trainer:
                 loader = tqdm.tqdm(self.val_loader, disable=None)
             except Exception:
                 pass
+        if max_batches is not None:
+            loader = itertools.islice(loader, int(max_batches))
         with torch.no_grad(), trace_range("validate"):
-            for bi, (img, label) in enumerate(loader):
-                if max_batches is not None and bi >= max_batches:
-                    break
-                img = img.to(self.device, non_blocking=True)
-                label = label.to(self.device, non_blocking=True)
+            # the next batch's host-to-device copy runs on the copy stream under this batch's forward
+            for img, label in DevicePrefetcher(loader, self.device):
                 counter.add_tensor(self.engine.eval_step(img, label))
         counter.all_reduce()
         res = counter.result()
@@ -250,5 +250,10 @@ def run_worker(cfg: Dict[str, Any], info: dist_env.DistInfo, logger_queue=None, 
     if seed is not None:
         make_deterministic(seed, strict=cfg["runtime"].get("deterministic", False))
     trainer = Trainer(cfg, info, logger_queue, tb_writer_constructor, seed, log_dir, ops_backend)
+    if cfg["runtime"].get("eval_only", False):
+        trainer.validate()            # checkpoint evaluation: weights come from training.resume
+        if trainer.tb_writer is not None:
+            trainer.tb_writer.flush()
+        return trainer
     trainer.run()
     return trainer

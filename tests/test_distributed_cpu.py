@@ -189,6 +189,26 @@ def test_cli_two_process_run_validation_checkpoint_resume(tmp_path):
     assert lr2[3] == pytest.approx(0.02) and lr2[4] == pytest.approx(0.002)
 
 
+def test_eval_only_evaluates_a_checkpoint(tmp_path):
+    """--eval-only: one validation pass over the weights in training.resume, no training iterations."""
+    cfg = _trainer_cfg(str(tmp_path), {"train_iters": 2, "val_interval": 2, "sync_bn": False})
+    log_dir = os.path.join(tmp_path, "run")
+    base = ["--cfg-filepath", cfg, "--dist-backend", "gloo", "--file-name-cfg", "t"]
+    res = _run_cli([*base, "--log-dir", log_dir])
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    ck = os.path.join(log_dir, "checkpoints", "iter_2.pth")
+    trained = [s for s in _scalars(log_dir) if s["tag"] == "eval/Acc@1"][-1]
+    log_dir2 = os.path.join(tmp_path, "eval")
+    res = _run_cli([*base, "--log-dir", log_dir2, "--eval-only", "--set", f"training.resume={ck}"])
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    log = open(os.path.join(log_dir2, "t.log")).read()
+    assert "Resumed from" in log and log.count("Acc@1:") == 1 and "Iter [" not in log
+    sc = _scalars(log_dir2)
+    assert {s["tag"] for s in sc} == {"eval/Acc@1", "eval/Acc@5", "eval/loss"}
+    assert sc[0]["value"] == pytest.approx(trained["value"], abs=1e-6)       # same weights, same validation set
+    assert not os.path.exists(os.path.join(log_dir2, "checkpoints"))
+
+
 def test_fault_injection_fails_fast_and_keeps_logs(tmp_path):
     cfg = _trainer_cfg(str(tmp_path), {"train_iters": 50})
     log_dir = os.path.join(tmp_path, "run")
