@@ -15,6 +15,7 @@ timeout) leaves the caller on the library collective.
 from __future__ import annotations
 
 import ctypes
+import os
 import socket
 from typing import Optional
 
@@ -138,7 +139,10 @@ class XgmiAllReduce:
         dist.broadcast(ref, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
         ok = ok and bool(torch.equal(probe, ref)) and self.status() == 0
         agreed = _agree(1 if ok else 0, dist.ReduceOp.MIN, self.group, self.device) == 1
-        self._lib.pdt_car_set_timeout_ms(self._h, 2000)
+        # In production a rank may legitimately arrive late (rank 0 writing a checkpoint, a slow
+        # loader): wait as a library collective would, but not for ever -- a peer that never
+        # arrives (crashed process) must not leave a kernel spinning on the GPU.
+        self._lib.pdt_car_set_timeout_ms(self._h, int(os.environ.get("PDT_XGMI_TIMEOUT_MS", "20000")))
         return agreed
 
     def close(self) -> None:

@@ -139,12 +139,16 @@ class Trainer:
         if self.ckpt_dir is None:
             return None
         self.engine.prepare_validation()   # collective on every rank (buffer sync without SyncBN)
-        if self.rank != 0:
-            return None
-        path = os.path.join(self.ckpt_dir, f"{tag or 'iter_%d' % (self.iter + 1)}.pth")
-        ckpt_io.save_checkpoint(path, self.engine.model_state_dict(), self.engine.optimizer_state_dict(),
-                                self.scheduler.state_dict(), self.iter + 1, self.cfg)
-        self.logger.info("Saved checkpoint %s", path)
+        path = None
+        if self.rank == 0:
+            path = os.path.join(self.ckpt_dir, f"{tag or 'iter_%d' % (self.iter + 1)}.pth")
+            ckpt_io.save_checkpoint(path, self.engine.model_state_dict(), self.engine.optimizer_state_dict(),
+                                    self.scheduler.state_dict(), self.iter + 1, self.cfg)
+            self.logger.info("Saved checkpoint %s", path)
+        if self.world > 1:
+            # the other ranks wait here, on the host, rather than inside the next step's first
+            # statistics exchange on the GPU
+            dist.barrier()
         return path
 
     # ------------------------------------------------------------------------------ loop
