@@ -158,6 +158,7 @@ class NativeResNet:
         # the incoming gradient (saves the reduction pass over g and y).
         self._fused_bwd_stats = bool(getattr(ops, "fused_bwd_stats", False)) and self.device.type == "cuda" \
             and os.environ.get("PDT_FUSED_BWD_STATS", "1") == "1"
+        self._fused_pool_bwd = os.environ.get("PDT_FUSED_POOL_BWD", "1") == "1"
         # Step replay (see .graphs): the second step of a batch signature is recorded, later ones
         # replay the record.  "list": a command list of the backend's own launches (default);
         # "graph": HIP graphs separated by host actions.  PDT_HIP_GRAPHS: 0 = off, 1 = on,
@@ -336,17 +337,22 @@ class NativeResNet:
         ctx.count = count
 
     def _bn_backward(self, u: ConvBNSpec, ctx: _UnitCtx, g: torch.Tensor, mask_src, mask_mode: int,
-                     prereduced: bool = False) -> torch.Tensor:
+                     prereduced: bool = False, pool_idx=None) -> torch.Tensor:
         """Gradient w.r.t. the raw conv output; accumulates dgamma / dbeta into the flat buffer.
         ``prereduced``: the data-gradient kernel that produced ``g`` already accumulated this
-        layer's sums (see :meth:`_bstats`), the reduction pass over ``g`` and ``y`` is skipped."""
+        layer's sums (see :meth:`_bstats`), the reduction pass over ``g`` and ``y`` is skipped.
+        ``pool_idx``: ``g`` is the gradient of the max pooling behind this layer's ReLU (the stem);
+        both passes gather the dense gradient from it instead of reading a materialised one."""
         P, ops = self.params, self.ops
         kw = {"prereduced": True} if prereduced else {}
+        ekw = {}
+        if pool_idx is not None:
+            kw["pool_idx"] = ekw["pool_idx"] = pool_idx
         if self.sync_bn and self._xgmi is not None and self._fused_stats:
             sums = ops.bn_bwd_reduce(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, mask_src, mask_mode,
                                      P.grad(f"{u.bn}.weight"), P.grad(f"{u.bn}.bias"), comm=self._xgmi, **kw)
             return ops.bn_bwd_elemt(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, sums, 1.0 / ctx.count,
-                                    mask_src, mask_mode)
+                                    mask_src, mask_mode, **ekw)
         sums = ops.bn_bwd_reduce(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, mask_src, mask_mode,
                                  P.grad(f"{u.bn}.weight"), P.grad(f"{u.bn}.bias"), **kw)
         if self.sync_bn:
@@ -366,7 +372,7 @@ class NativeResNet:
             else:
                 self._host(lambda: dist.all_reduce(sums, group=group))
         return ops.bn_bwd_elemt(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, sums, 1.0 / ctx.count,
-                                mask_src, mask_mode)
+                                mask_src, mask_mode, **ekw)
 
     def _wgrad(self, fn) -> None:
         """Run a weight-gradient closure now, or (SyncBN) hold it back until the next statistics
@@ -655,9 +661,14 @@ class NativeResNet:
                 g = self._block_backward(blocks[j], g, pre, prev_last)
                 pre = prev_last is not None and self._fused_bwd_stats
             stem = self.spec.stem
-            da = ops.maxpool_bwd(g, self._saved.pop("pool_idx"), self._saved.pop("stem_shape"))
             ctx = self._ctx.pop(stem.bn)
-            dy = self._bn_backward(stem, ctx, da, None, MASK_RECOMPUTE)
+            pool_idx, stem_shape = self._saved.pop("pool_idx"), self._saved.pop("stem_shape")
+            if self._fused_pool_bwd:
+                # the dense 112x112 gradient of the pooling is never materialised
+                dy = self._bn_backward(stem, ctx, g, None, MASK_RECOMPUTE, pool_idx=pool_idx)
+            else:
+                da = ops.maxpool_bwd(g, pool_idx, stem_shape)
+                dy = self._bn_backward(stem, ctx, da, None, MASK_RECOMPUTE)
             self._run_deferred()
             self._join_wgrad()
             ops.stem_wgrad(ctx.x_in, dy, P.grad("conv1.weight"))

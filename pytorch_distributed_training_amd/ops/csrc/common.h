@@ -32,6 +32,42 @@ __device__ __forceinline__ bf16x8 ld_stream_bf16x8(const bf16* p) {
     return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
 }
 
+// Gradient of a 3x3 / stride 2 / pad 1 max pooling at input element (b, h, w), channel vector cv:
+// the sum of the gradients of the (at most 2 x 2) windows whose stored winner position (0..8,
+// one byte per channel, packed 8 to a 64-bit word) is this element.  A gather, so the dense
+// H x W gradient never has to exist in memory.
+__device__ __forceinline__ void pool3x3s2_grad8(const bf16* __restrict__ dout, const unsigned char* __restrict__ idx,
+                                                int b, int h, int w, int cv, int cvec, int Ho, int Wo,
+                                                float (&acc)[8]) {
+    // windows (ho, wo) covering (h, w): ho*2-1 <= h <= ho*2+1, i.e. ho in {h>>1, (h+1)>>1}.  All four
+    // candidates are loaded unconditionally (a candidate that does not exist re-reads the first one
+    // and is given a winner code no window can hold), so the loads go out back to back.
+    const int ho0 = h >> 1, wo0 = w >> 1;
+    const int ho1 = (h + 1) >> 1, wo1 = (w + 1) >> 1;
+    const bool vh = ho1 != ho0 && ho1 < Ho, vw = wo1 != wo0 && wo1 < Wo;
+    const int hs[2] = {ho0, vh ? ho1 : ho0}, ws[2] = {wo0, vw ? wo1 : wo0};
+    unsigned long long packed[4];
+    bf16x8 gv[4];
+    unsigned want[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ho = hs[q >> 1], wo = ws[q & 1];
+        const bool valid = ((q >> 1) == 0 || vh) && ((q & 1) == 0 || vw);
+        want[q] = valid ? (unsigned)((h - (ho * 2 - 1)) * 3 + (w - (wo * 2 - 1))) : 0xffu;
+        const long long o = (((long long)b * Ho + ho) * Wo + wo) * cvec + cv;
+        packed[q] = reinterpret_cast<const unsigned long long*>(idx)[o];
+        gv[q] = *reinterpret_cast<const bf16x8*>(dout + o * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float a = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            a += ((unsigned)((packed[q] >> (8 * k)) & 0xff) == want[q]) ? (float)gv[q][k] : 0.0f;
+        acc[k] = a;
+    }
+}
+
 __device__ __forceinline__ bf16x8 zero_bf16x8() {
     bf16x8 z;
 #pragma unroll

@@ -361,6 +361,62 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16* __restrict
     }
 }
 
+// BatchNorm backward elementwise pass of the layer under a fused ReLU + max pooling, from the POOLED
+// gradient: dx = poolgrad*[y*scale+shift > 0]*A + y*Bc + Cc (coefficients as in bn_bwd_elemt).
+__global__ __launch_bounds__(256) void pool_bn_bwd_elemt_kernel(
+    const bf16* __restrict__ dout, const unsigned char* __restrict__ idx, const bf16* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ sums, float inv_count, bf16* __restrict__ dx,
+    long long nvec, int cvec, int C, int H, int W, int Ho, int Wo) {
+    long long stride = (long long)gridDim.x * blockDim.x;
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nvec) return;
+    const int cv = (int)((nvec - 1 - t) % cvec);        // the grid stride is a multiple of cvec
+    const int c0 = cv * 8;
+    float A[8], Bc[8], Cc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float s0 = sums[c0 + k] * inv_count, s1 = sums[C + c0 + k] * inv_count;
+        float sc = scale[c0 + k], is = invstd[c0 + k], mu = mean[c0 + k];
+        A[k] = sc;
+        Bc[k] = -is * s1 * sc;
+        Cc[k] = (mu * is * s1 - s0) * sc;
+        sh[k] = shift[c0 + k];
+    }
+    for (; t < nvec; t += stride) {
+        const long long i = nvec - 1 - t;               // back to front, like bn_bwd_elemt
+        long long r = i / cvec;
+        int w = (int)(r % W);
+        r /= W;
+        int h = (int)(r % H);
+        int b = (int)(r / H);
+        bf16x8 yv = ld_stream_bf16x8(y + i * 8);
+        float g[8];
+        pool3x3s2_grad8(dout, idx, b, h, w, cv, cvec, Ho, Wo, g);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float yy = bf2f(yv[k]);
+            float dy = (yy * A[k] + sh[k]) > 0.0f ? g[k] : 0.0f;
+            o[k] = f2bf(dy * A[k] + yy * Bc[k] + Cc[k]);
+        }
+        st_bf16x8(dx + i * 8, o);
+    }
+}
+
+PDT_API int pdt_pool_bn_bwd_elemt(const void* dout, const void* idx, const void* y, const float* mean,
+                                  const float* invstd, const float* scale, const float* shift, const float* sums,
+                                  float inv_count, void* dx, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s) {
+    if (C % 8 != 0 || C / 8 > 256 || 256 % (C / 8) != 0) return -1;
+    if (Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1 || B < 1) return -2;
+    int cvec = C / 8;
+    long long nvec = (long long)B * H * W * cvec;
+    hipLaunchKernelGGL(pool_bn_bwd_elemt_kernel, dim3(ew_grid(nvec, 4)), dim3(256), 0, s, (const bf16*)dout,
+                       (const unsigned char*)idx, (const bf16*)y, mean, invstd, scale, shift, sums, inv_count,
+                       (bf16*)dx, nvec, cvec, C, H, W, Ho, Wo);
+    return pdt_launch_status();
+}
+
 PDT_API int pdt_maxpool_fwd(const void* x, void* out, void* idx, int B, int H, int W, int C, int Ho, int Wo,
                             hipStream_t s) {
     if (C % 8) return -1;

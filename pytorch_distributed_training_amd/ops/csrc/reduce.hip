@@ -303,6 +303,65 @@ PDT_API int pdt_bn_bwd_reduce_accum(const void* g, const void* y, const void* ms
     return pdt_launch_status();
 }
 
+// The same sums for the BatchNorm under a fused ReLU + 3x3/s2 max pooling (the ResNet stem), taken
+// straight from the POOLED gradient and the pooling's winner indices: dy = poolgrad * [y*scale +
+// shift > 0].  The dense H x W gradient is neither written nor read.
+__global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(
+    const bf16* __restrict__ dout, const unsigned char* __restrict__ idx, const bf16* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ scale, const float* __restrict__ shift,
+    float* __restrict__ acc, long long rows, int C, int H, int W, int Ho, int Wo, int cv, int rl, int slabs,
+    int rows_per_block) {
+    int slab = blockIdx.x % slabs;
+    int chunk = blockIdx.x / slabs;
+    int col_lane = threadIdx.x % cv;
+    int row_lane = threadIdx.x / cv;
+    int c_base = slab * cv * 8;
+    int c0 = c_base + col_lane * 8;
+    const int cvec = C / 8;
+    float mu[8], sc[8], sh[8], a0[8], a1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mu[k] = mean[c0 + k];
+        sc[k] = scale[c0 + k];
+        sh[k] = shift[c0 + k];
+        a0[k] = 0.0f;
+        a1[k] = 0.0f;
+    }
+    long long r0 = (long long)chunk * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (long long r = r0 + row_lane; r < r1; r += rl) {
+        int w = (int)(r % W);
+        long long t = r / W;
+        int h = (int)(t % H);
+        int b = (int)(t / H);
+        bf16x8 yv = ld_bf16x8(y + r * C + c0);
+        float g[8];
+        pool3x3s2_grad8(dout, idx, b, h, w, c0 / 8, cvec, Ho, Wo, g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float yy = bf2f(yv[k]);
+            float dy = (yy * sc[k] + sh[k]) > 0.0f ? g[k] : 0.0f;
+            a0[k] += dy;
+            a1[k] += dy * (yy - mu[k]);
+        }
+    }
+    block_col_reduce_atomic(a0, a1, cv, rl, col_lane, row_lane, c_base, C, acc);
+}
+
+PDT_API int pdt_pool_bn_bwd_reduce_accum(const void* dout, const void* idx, const void* y, const float* mean,
+                                         const float* scale, const float* shift, float* acc, int B, int H, int W,
+                                         int C, int Ho, int Wo, hipStream_t s) {
+    if (C % 8 != 0 || (C / 8 < 32 ? 256 % (C / 8) != 0 : (C / 8) % 32 != 0)) return -1;
+    if (Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1 || B < 1) return -2;
+    long long rows = (long long)B * H * W;
+    ColGeom gm = col_geom(rows, C);
+    hipLaunchKernelGGL(pool_bn_bwd_reduce_kernel, dim3(gm.slabs * gm.row_chunks), dim3(256), 0, s, (const bf16*)dout,
+                       (const unsigned char*)idx, (const bf16*)y, mean, scale, shift, acc, rows, C, H, W, Ho, Wo, gm.cv,
+                       gm.rl, gm.slabs, gm.rows_per_block);
+    return pdt_launch_status();
+}
+
 // replicas -> sums [sum(dy), sum(dy*xhat)] ; dbeta += sums[0], dgamma += sums[1] ; zero replicas
 __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(float* __restrict__ acc, const float* __restrict__ invstd,
                                                            float* __restrict__ sums, float* __restrict__ dgamma,

@@ -46,6 +46,8 @@ _sig("pdt_input_pad", _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, 
 _sig("pdt_maxpool_fwd", _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
 _sig("pdt_bn_relu_maxpool_fwd", _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
 _sig("pdt_maxpool_bwd", _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
+_sig("pdt_pool_bn_bwd_reduce_accum", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
+_sig("pdt_pool_bn_bwd_elemt", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _vp)
 _sig("pdt_avgpool_fwd", _vp, _vp, _i, _i, _i, _vp)
 _sig("pdt_avgpool_bwd", _vp, _vp, _vp, _i, _i, _i, _vp)
 _sig("pdt_transpose_w", _vp, _vp, _i, _i, _i, _i, _vp)
@@ -610,12 +612,22 @@ batch_chunks = True          # ops take out= destinations, so a batch can be pro
 fused_bwd_stats = True       # conv_dgrad(bwd_stats=...) + bn_bwd_reduce(prereduced=True)
 
 
+def _pool_geometry(dout, y, what: str):
+    """Shapes of the pooled gradient ``dout`` against the pooling's input ``y`` (3x3 / s2 / p1)."""
+    B, H, W, C = y.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    if tuple(dout.shape) != (B, Ho, Wo, C):
+        raise ValueError(f"{what}: pooled gradient {tuple(dout.shape)} does not belong to an input {tuple(y.shape)}")
+    return B, H, W, C, Ho, Wo
+
+
 def bn_bwd_reduce(g, y, mean, invstd, scale, shift, mask_src, mask_mode: int, dgamma=None, dbeta=None, comm=None,
-                  prereduced: bool = False):
+                  prereduced: bool = False, pool_idx=None):
     """``comm`` (an ``XgmiAllReduce``): the returned sums are already summed over its ranks (the
     exchange runs inside the kernel that folds the accumulator replicas).  ``prereduced``: the
     accumulator already holds this layer's sums (the data-gradient epilogue that produced ``g``
-    put them there), only the fold remains."""
+    put them there), only the fold remains.  ``pool_idx``: ``g`` is the gradient of the max
+    pooling that follows this layer's ReLU; the dense gradient is gathered on the fly."""
     g = _bf16c(g, "bn_bwd_reduce g")
     y = _bf16c(y, "bn_bwd_reduce y")
     if mask_mode == MASK_TENSOR:
@@ -623,7 +635,14 @@ def bn_bwd_reduce(g, y, mean, invstd, scale, shift, mask_src, mask_mode: int, dg
     C = y.shape[-1]
     rows = y.numel() // C
     acc = _accumulator(y.device, C, "bwd")
-    if not prereduced:
+    if pool_idx is not None:
+        if mask_mode != MASK_RECOMPUTE or prereduced:
+            raise ValueError("bn_bwd_reduce: pool_idx goes with the recomputed ReLU mask")
+        B, H, W, _, Ho, Wo = _pool_geometry(g, y, "bn_bwd_reduce")
+        rc = _lib.pdt_pool_bn_bwd_reduce_accum(_p(g), _p(pool_idx), _p(y), _p(mean), _p(scale), _p(shift), _p(acc),
+                                               B, H, W, C, Ho, Wo, _stream())
+        _check(rc, "pdt_pool_bn_bwd_reduce_accum")
+    elif not prereduced:
         rc = _lib.pdt_bn_bwd_reduce_accum(_p(g), _p(y), _p(mask_src) if mask_mode == MASK_TENSOR else None, _p(mean),
                                           _p(scale), _p(shift), _p(acc), rows, C, mask_mode, _stream())
         _check(rc, "pdt_bn_bwd_reduce_accum")
@@ -641,11 +660,19 @@ def bn_bwd_reduce(g, y, mean, invstd, scale, shift, mask_src, mask_mode: int, dg
 
 
 def bn_bwd_elemt(g, y, mean, invstd, scale, shift, sums, inv_count: float, mask_src, mask_mode: int,
-                 out: Optional[torch.Tensor] = None):
+                 out: Optional[torch.Tensor] = None, pool_idx=None):
     g = _bf16c(g, "bn_bwd_elemt g")
     y = _bf16c(y, "bn_bwd_elemt y")
     C = y.shape[-1]
     dx = _out_like(out, y.shape, y.device, "bn_bwd_elemt")
+    if pool_idx is not None:
+        if mask_mode != MASK_RECOMPUTE:
+            raise ValueError("bn_bwd_elemt: pool_idx goes with the recomputed ReLU mask")
+        B, H, W, _, Ho, Wo = _pool_geometry(g, y, "bn_bwd_elemt")
+        rc = _lib.pdt_pool_bn_bwd_elemt(_p(g), _p(pool_idx), _p(y), _p(mean), _p(invstd), _p(scale), _p(shift),
+                                        _p(sums), inv_count, _p(dx), B, H, W, C, Ho, Wo, _stream())
+        _check(rc, "pdt_pool_bn_bwd_elemt")
+        return dx
     rc = _lib.pdt_bn_bwd_elemt(_p(g), _p(y), _p(mask_src) if mask_mode == MASK_TENSOR else None, _p(mean), _p(invstd),
                                _p(scale), _p(shift), _p(sums), inv_count, _p(dx), y.numel() // C, C, mask_mode,
                                _stream())

@@ -196,12 +196,17 @@ def bn_apply2(y, scale, shift, y2, scale2, shift2, relu: bool):
 
 
 def bn_bwd_reduce(g, y, mean, invstd, scale, shift, mask_src, mask_mode: int,
-                  dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None,
+                  pool_idx=None) -> torch.Tensor:
     """``[2, C]``: local ``sum(dy)`` and ``sum(dy * xhat)`` with ``xhat = (y - mean) * invstd``.
 
     When given, ``dbeta += sum(dy)`` and ``dgamma += sum(dy * xhat)`` (the LOCAL sums are the
     parameter gradients; the bucketed all-reduce averages them over ranks later).
+    ``pool_idx``: ``g`` is the gradient of the 3x3/s2 max pooling that follows this layer's ReLU
+    (with the pooling's index tensor), not of the activation itself.
     """
+    if pool_idx is not None:
+        g = maxpool_bwd(g, pool_idx, tuple(y.shape))
     y32 = y.float()
     dy = _masked(g, y32, scale, shift, mask_src, mask_mode)
     xhat = (y32 - mean) * invstd
@@ -214,13 +219,16 @@ def bn_bwd_reduce(g, y, mean, invstd, scale, shift, mask_src, mask_mode: int,
     return sums
 
 
-def bn_bwd_elemt(g, y, mean, invstd, scale, shift, sums, inv_count: float, mask_src, mask_mode: int) -> torch.Tensor:
+def bn_bwd_elemt(g, y, mean, invstd, scale, shift, sums, inv_count: float, mask_src, mask_mode: int,
+                 pool_idx=None) -> torch.Tensor:
     """``dx = (dy - s0 - xhat * s1) * scale`` with ``[s0, s1] = sums * inv_count``.
 
     ``sums`` are the (all-reduced) global sums from :func:`bn_bwd_reduce` and ``inv_count`` is
     one over the GLOBAL number of elements per channel
-    (``torch/nn/modules/_functions.py:170-179``).
+    (``torch/nn/modules/_functions.py:170-179``).  ``pool_idx``: as in :func:`bn_bwd_reduce`.
     """
+    if pool_idx is not None:
+        g = maxpool_bwd(g, pool_idx, tuple(y.shape))
     y32 = y.float()
     dy = _masked(g, y32, scale, shift, mask_src, mask_mode)
     xhat = (y32 - mean) * invstd

@@ -309,6 +309,40 @@ def test_pooling(hip, device, B, H, C):
     assert rel_err(hip.avgpool_bwd(dp, H, H, mk), ref.avgpool_bwd(dp, H, H, mk)) < 1e-2
 
 
+@pytest.mark.parametrize("B,H,C", [(2, 112, 64), (3, 30, 64), (1, 9, 128)])
+def test_bn_backward_through_fused_relu_maxpool(hip, device, B, H, C):
+    """BatchNorm-backward passes fed with the POOLED gradient + winner indices against the
+    materialised pooling gradient followed by the ordinary passes."""
+    torch.manual_seed(B * H + C)
+    y = rnd(B, H, H, C, device=device)
+    gamma = torch.rand(C, device=device) + 0.5
+    beta = torch.randn(C, device=device) * 0.2
+    mean = y.float().mean(dim=(0, 1, 2))
+    invstd = (y.float().var(dim=(0, 1, 2), unbiased=False) + 1e-5).rsqrt()
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    pooled, idx = hip.bn_relu_maxpool_fwd(y, scale, shift)
+    dout = rnd(*pooled.shape, device=device)
+    # the dense path: pooling gradient materialised (bf16), then the ordinary reduce / elementwise passes
+    dense = hip.maxpool_bwd(dout, idx, tuple(y.shape))
+    dg0, db0 = torch.zeros(C, device=device), torch.zeros(C, device=device)
+    sums0 = hip.bn_bwd_reduce(dense, y, mean, invstd, scale, shift, None, ref.MASK_RECOMPUTE, dg0, db0)
+    dx0 = hip.bn_bwd_elemt(dense, y, mean, invstd, scale, shift, sums0, 1.0 / (B * H * H), None, ref.MASK_RECOMPUTE)
+    dg1, db1 = torch.zeros(C, device=device), torch.zeros(C, device=device)
+    sums1 = hip.bn_bwd_reduce(dout, y, mean, invstd, scale, shift, None, ref.MASK_RECOMPUTE, dg1, db1, pool_idx=idx)
+    dx1 = hip.bn_bwd_elemt(dout, y, mean, invstd, scale, shift, sums1, 1.0 / (B * H * H), None, ref.MASK_RECOMPUTE,
+                           pool_idx=idx)
+    tol = dict(rtol=2e-2, atol=2e-2 * sums0.abs().max().item())      # dense rounds the summed gradient to bf16
+    assert torch.allclose(sums1, sums0, **tol) and torch.allclose(dg1, dg0, **tol) and torch.allclose(db1, db0, **tol)
+    assert rel_err(dx1, dx0) < 2e-2
+    # and against the fp32 reference ops on the same pooled gradient
+    pooled_r, idx_r = ref.bn_relu_maxpool_fwd(y, scale, shift)
+    sums_r = ref.bn_bwd_reduce(dout, y, mean, invstd, scale, shift, None, ref.MASK_RECOMPUTE, pool_idx=idx_r)
+    dx_r = ref.bn_bwd_elemt(dout, y, mean, invstd, scale, shift, sums_r, 1.0 / (B * H * H), None, ref.MASK_RECOMPUTE,
+                            pool_idx=idx_r)
+    assert torch.allclose(sums1, sums_r, **tol)
+    assert rel_err(dx1, dx_r) < 2e-2
+
+
 @pytest.mark.parametrize("B,K,N", [(64, 2048, 1000), (7, 512, 10)])
 def test_classifier_and_loss(hip, device, B, K, N):
     torch.manual_seed(B + N)
