@@ -433,8 +433,10 @@ def _out_like(out: Optional[torch.Tensor], shape, device, what: str) -> torch.Te
 
 # Static per-shape tile selection (what upstream leaves to cudnn.benchmark autotuning): shapes on
 # which the 64x128 tile measured faster than the launcher's own choice at per-GPU batch 256
-# (bench/conv_layers.py --tile sweep).  Key: (op, Cin, Cout, k, stride, input H).  Only applied to
-# large batches (the measurement's regime); everything else uses the launcher's heuristic.
+# (bench/conv_layers.py --tile sweep).  Key: (op, Cin, Cout, k, stride, input H).  Only applied in
+# the measurement's regime (per-GPU batch 192..383: the 14x14 / 7x7 layers then have too few
+# 128x128 tiles to fill the chip evenly); at batch 512 the same sweep prefers the launcher's own
+# choice on every layer, and small batches use the launcher's heuristic too.
 _TILE_HINTS = {
     ("fprop", 256, 256, 3, 2, 28): 5, ("fprop", 1024, 256, 1, 1, 14): 5, ("fprop", 256, 256, 3, 1, 14): 5,
     ("dgrad", 128, 128, 3, 2, 56): 5, ("dgrad", 256, 256, 3, 2, 28): 5, ("dgrad", 256, 1024, 1, 1, 14): 5,
@@ -443,7 +445,7 @@ _TILE_HINTS = {
 
 
 def _tile_hint(op: str, B: int, Ci: int, Co: int, k: int, stride: int, H: int) -> int:
-    return _TILE_HINTS.get((op, Ci, Co, k, stride, H), 0) if B >= 192 else 0
+    return _TILE_HINTS.get((op, Ci, Co, k, stride, H), 0) if 192 <= B < 384 else 0
 
 
 # --------------------------------------------------------------------------- convolution
