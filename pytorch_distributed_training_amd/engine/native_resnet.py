@@ -159,6 +159,9 @@ class NativeResNet:
         self._fused_bwd_stats = bool(getattr(ops, "fused_bwd_stats", False)) and self.device.type == "cuda" \
             and os.environ.get("PDT_FUSED_BWD_STATS", "1") == "1"
         self._fused_pool_bwd = os.environ.get("PDT_FUSED_POOL_BWD", "1") == "1"
+        # ReLU backward of a block output from a packed bit mask written by the pass that produced
+        # the tensor, instead of re-reading the tensor for its sign in the data-gradient epilogue.
+        self._relu_bits = bool(getattr(ops, "relu_bits", False)) and os.environ.get("PDT_RELU_BITS", "1") == "1"
         # Step replay (see .graphs): the second step of a batch signature is recorded, later ones
         # replay the record.  "list": a command list of the backend's own launches (default);
         # "graph": HIP graphs separated by host actions.  PDT_HIP_GRAPHS: 0 = off, 1 = on,
@@ -453,14 +456,16 @@ class NativeResNet:
         B = y.shape[0]
         step = B // n
         out = torch.empty_like(y)
+        bits = self._new_bits(out, train)
         ys, stats = {}, {}
         for c in range(n):
             sl = slice(c * step, (c + 1) * step)
+            bkw = {"bits_out": bits[sl]} if bits is not None else {}
             if kind == "apply2":
                 y2, sc2, sh2 = extra
-                ops.bn_apply2(y[sl], scale, shift, y2[sl], sc2, sh2, True, out=out[sl])
+                ops.bn_apply2(y[sl], scale, shift, y2[sl], sc2, sh2, True, out=out[sl], **bkw)
             else:
-                ops.bn_apply(y[sl], scale, shift, extra[sl] if extra is not None else None, True, out=out[sl])
+                ops.bn_apply(y[sl], scale, shift, extra[sl] if extra is not None else None, True, out=out[sl], **bkw)
             for k, u in enumerate(users):
                 w = self.params.compute(f"{u.conv}.weight")
                 Ho = (y.shape[1] + 2 * u.pad - u.ksize) // u.stride + 1
@@ -502,17 +507,32 @@ class NativeResNet:
                 ("apply", y, scale, shift, identity)
             if self._can_slice(train) and self._n_slices(y) > 1 and b is not self.spec.blocks[-1]:
                 return tail                 # applied by the next block, slice by slice with its convs
-            return self._apply_tail(tail)
+            return self._apply_tail(tail, train)
         return out
 
     def _can_slice(self, train: bool) -> bool:
         return self._slice_bytes > 0 and (self._fused_stats or not train)
 
-    def _apply_tail(self, tail) -> torch.Tensor:
+    def _new_bits(self, out: torch.Tensor, train: bool):
+        """Packed ReLU mask of a block output (one byte per 8 channels), attached to the tensor: the
+        data-gradient kernel that applies this ReLU's backward reads it instead of the tensor."""
+        if not (train and self._relu_bits):
+            return None
+        bits = self.ops.new_relu_bits(out)
+        out._pdt_relu_bits = bits
+        return bits
+
+    def _apply_tail(self, tail, train: bool = False) -> torch.Tensor:
         kind, y, scale, shift, extra = tail
+        bits = self.ops.new_relu_bits(y) if (train and self._relu_bits) else None
+        kw = {"bits_out": bits} if bits is not None else {}
         if kind == "apply2":
-            return self.ops.bn_apply2(y, scale, shift, *extra, True)
-        return self.ops.bn_apply(y, scale, shift, extra, True)
+            out = self.ops.bn_apply2(y, scale, shift, *extra, True, **kw)
+        else:
+            out = self.ops.bn_apply(y, scale, shift, extra, True, **kw)
+        if bits is not None:
+            out._pdt_relu_bits = bits
+        return out
 
     def forward(self, img: torch.Tensor, train: Optional[bool] = None) -> torch.Tensor:
         """Logits ``[B, num_classes]`` for a loader batch (float NCHW or uint8 NHWC)."""
@@ -542,7 +562,7 @@ class NativeResNet:
             for b in self.spec.blocks:
                 x = self._block_forward(b, x, train)
             if isinstance(x, tuple):
-                x = self._apply_tail(x)
+                x = self._apply_tail(x, train)
             pooled = ops.avgpool_fwd(x)
             if train:
                 self._saved["final_hw"] = (x.shape[1], x.shape[2])
@@ -638,8 +658,10 @@ class NativeResNet:
             other = g                       # identity path
         # x_block is a post-ReLU tensor (previous block output, or the max-pooled stem activation,
         # where a zero means the whole pooling window was zero): apply its ReLU backward here.
+        bits = getattr(x_block, "_pdt_relu_bits", None)
+        mkw = {"relu_bits": bits} if bits is not None else {"relu_mask": x_block}
         return ops.conv_dgrad(dy_first, P.compute(key0), self._wt_view(key0), tuple(x_block.shape),
-                              u0.ksize, u0.ksize, u0.stride, u0.pad, addend=other, relu_mask=x_block,
+                              u0.ksize, u0.ksize, u0.stride, u0.pad, addend=other, **mkw,
                               **(self._bstats(prev_last, MASK_NONE) or {}))
 
     def backward(self, dlogits: torch.Tensor) -> None:

@@ -64,6 +64,7 @@ struct IgemmParams {
     int Ho, Wo, OS, oy0, ox0;
     int N, ldo, wrow, T;
     int simple_out;
+    int mask_bits;                     // mask points to packed ReLU bits (1 byte per 8 channels), not to a tensor
     // one 32-bit word per tap: offy (int8) | offx (int8) << 8 | widx (uint16) << 16.  Sub-dword
     // entries would be fetched with VECTOR loads (no scalar byte loads on gfx9), whose waits
     // drain the tile prefetches; a dword indexed by a wave-uniform tap is one s_load_dword.
@@ -403,9 +404,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
                 bf16x8 yv;
                 if (bwd_stats) yv = ld_bf16x8(p.bstat_y + o);
                 if (p.mask) {
-                    bf16x8 mk = ld_bf16x8(p.mask + o);
+                    if (p.mask_bits) {
+                        unsigned mb = reinterpret_cast<const unsigned char*>(p.mask)[o >> 3];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) ov[k] = bf2f(mk[k]) > 0.0f ? ov[k] : f2bf(0.0f);
+                        for (int k = 0; k < 8; ++k) ov[k] = ((mb >> k) & 1u) ? ov[k] : f2bf(0.0f);
+                    } else {
+                        bf16x8 mk = ld_bf16x8(p.mask + o);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) ov[k] = bf2f(mk[k]) > 0.0f ? ov[k] : f2bf(0.0f);
+                    }
                 }
                 st_bf16x8(p.out + o, ov);
                 if (bwd_stats) {
@@ -496,7 +503,7 @@ static int launch_igemm(const IgemmParams& p, hipStream_t s) {
 
 // tile: 0 = auto, 1 = 128x128x64, 2 = 128x64x64, 3 = 64x64x64, 4 = 128x64x32 (stem), 5 = 64x128x64
 static int conv_igemm_impl(const void* in, const void* wgt, void* out, const void* addend, const void* mask,
-                           const float* bias, float* stat_acc, const float* stat_shift, const void* bstat_y,
+                           int mask_bits, const float* bias, float* stat_acc, const float* stat_shift, const void* bstat_y,
                            const float* bstat_mean, const float* bstat_scale, const float* bstat_shift, long long M,
                            int Hi, int Wi, int pix_stride, int Ci, int Hg, int Wg, int IS, int Ho, int Wo, int OS,
                            int oy0, int ox0, int N, int ldo, int wrow, int T, const signed char* offy,
@@ -521,6 +528,8 @@ static int conv_igemm_impl(const void* in, const void* wgt, void* out, const voi
     }
     p.Hg = Hg; p.Wg = Wg; p.IS = IS; p.Ho = Ho; p.Wo = Wo; p.OS = OS; p.oy0 = oy0; p.ox0 = ox0;
     p.N = N; p.ldo = ldo; p.wrow = wrow; p.T = T;
+    p.mask_bits = (mask && mask_bits) ? 1 : 0;
+    if (p.mask_bits && ldo != N) return -8;        // the bit image is indexed like a dense [rows][N] tensor
     p.simple_out = (OS == 1 && oy0 == 0 && ox0 == 0 && Hg == Ho && Wg == Wo) ? 1 : 0;
     for (int i = 0; i < T; ++i)
         p.taps[i] = ((int)offy[i] & 0xff) | (((int)offx[i] & 0xff) << 8) | ((int)widx[i] << 16);
@@ -549,11 +558,12 @@ static int conv_igemm_impl(const void* in, const void* wgt, void* out, const voi
 }
 
 PDT_API int pdt_conv_igemm(const void* in, const void* wgt, void* out, const void* addend, const void* mask,
-                           const float* bias, float* stat_acc, const float* stat_shift, long long M, int Hi, int Wi,
+                           int mask_bits, const float* bias, float* stat_acc, const float* stat_shift, long long M, int Hi, int Wi,
                            int pix_stride, int Ci, int Hg, int Wg, int IS, int Ho, int Wo, int OS, int oy0, int ox0,
                            int N, int ldo, int wrow, int T, const signed char* offy, const signed char* offx,
                            const unsigned short* widx, int tile, hipStream_t s) {
-    return conv_igemm_impl(in, wgt, out, addend, mask, bias, stat_acc, stat_shift, nullptr, nullptr, nullptr, nullptr, M,
+    return conv_igemm_impl(in, wgt, out, addend, mask, mask_bits, bias, stat_acc, stat_shift, nullptr, nullptr, nullptr,
+                           nullptr, M,
                            Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, ldo, wrow, T, offy, offx, widx,
                            tile, s);
 }
@@ -561,12 +571,12 @@ PDT_API int pdt_conv_igemm(const void* in, const void* wgt, void* out, const voi
 // Data gradient whose epilogue also accumulates the BatchNorm-backward sums of the consuming layer
 // (see IgemmParams::bstat_y).
 PDT_API int pdt_conv_igemm_bstats(const void* in, const void* wgt, void* out, const void* addend, const void* mask,
-                                  float* stat_acc, const void* bstat_y, const float* bstat_mean,
+                                  int mask_bits, float* stat_acc, const void* bstat_y, const float* bstat_mean,
                                   const float* bstat_scale, const float* bstat_shift, long long M, int Hi, int Wi,
                                   int pix_stride, int Ci, int Hg, int Wg, int IS, int Ho, int Wo, int OS, int oy0,
                                   int ox0, int N, int ldo, int wrow, int T, const signed char* offy,
                                   const signed char* offx, const unsigned short* widx, int tile, hipStream_t s) {
-    return conv_igemm_impl(in, wgt, out, addend, mask, nullptr, stat_acc, nullptr, bstat_y, bstat_mean, bstat_scale,
+    return conv_igemm_impl(in, wgt, out, addend, mask, mask_bits, nullptr, stat_acc, nullptr, bstat_y, bstat_mean, bstat_scale,
                            bstat_shift, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, ldo, wrow, T, offy,
                            offx, widx, tile, s);
 }

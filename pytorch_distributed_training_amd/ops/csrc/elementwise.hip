@@ -66,7 +66,9 @@ template <bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ y, const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
                                                         const bf16* __restrict__ res, bf16* __restrict__ out,
-                                                        long long nvec, int cvec) {
+                                                        unsigned char* __restrict__ bits, long long nvec, int cvec) {
+    // bits (optional): one byte per 8-channel vector, bit k = [out channel k > 0] -- the ReLU mask
+    // backward needs, 1/16 of the tensor it would otherwise re-read for the sign.
     long long stride = (long long)gridDim.x * blockDim.x;
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nvec) return;
@@ -91,10 +93,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ 
             o[k] = f2bf(f);
         }
         st_bf16x8(out + i * 8, o);
+        if (bits) {
+            unsigned m = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m |= (bf2f(o[k]) > 0.0f ? 1u : 0u) << k;
+            bits[i] = (unsigned char)m;
+        }
     }
 }
 
-PDT_API int pdt_bn_apply(const void* y, const float* scale, const float* shift, const void* res, void* out,
+PDT_API int pdt_bn_apply(const void* y, const float* scale, const float* shift, const void* res, void* out, void* bits,
                          long long rows, int C, int relu, hipStream_t s) {
     // the grid stride (grid*256 vectors) must be a multiple of C/8 so channels stay fixed per thread
     if (C % 8 != 0 || C / 8 > 256 || 256 % (C / 8) != 0) return -1;
@@ -102,10 +110,11 @@ PDT_API int pdt_bn_apply(const void* y, const float* scale, const float* shift, 
     int cvec = C / 8;
     dim3 grid(ew_grid(nvec, 4)), block(256);
     const bf16* yy = (const bf16*)y; const bf16* rr = (const bf16*)res; bf16* oo = (bf16*)out;
-    if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, 0, s, yy, scale, shift, rr, oo, nvec, cvec);
-    else if (res) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, 0, s, yy, scale, shift, rr, oo, nvec, cvec);
-    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, block, 0, s, yy, scale, shift, rr, oo, nvec, cvec);
-    else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, 0, s, yy, scale, shift, rr, oo, nvec, cvec);
+    unsigned char* bb = (unsigned char*)bits;
+    if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, 0, s, yy, scale, shift, rr, oo, bb, nvec, cvec);
+    else if (res) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, 0, s, yy, scale, shift, rr, oo, bb, nvec, cvec);
+    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, block, 0, s, yy, scale, shift, rr, oo, bb, nvec, cvec);
+    else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, 0, s, yy, scale, shift, rr, oo, bb, nvec, cvec);
     return pdt_launch_status();
 }
 
@@ -115,7 +124,8 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const bf16* __restrict__
                                                          const float* __restrict__ shift,
                                                          const bf16* __restrict__ y2, const float* __restrict__ scale2,
                                                          const float* __restrict__ shift2, bf16* __restrict__ out,
-                                                         long long nvec, int cvec, int relu) {
+                                                         unsigned char* __restrict__ bits, long long nvec, int cvec,
+                                                         int relu) {
     long long stride = (long long)gridDim.x * blockDim.x;
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nvec) return;
@@ -139,15 +149,21 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const bf16* __restrict__
             o[k] = f2bf(f);
         }
         st_bf16x8(out + i * 8, o);
+        if (bits) {                                  // ReLU mask byte, as in bn_apply
+            unsigned m = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m |= (bf2f(o[k]) > 0.0f ? 1u : 0u) << k;
+            bits[i] = (unsigned char)m;
+        }
     }
 }
 
 PDT_API int pdt_bn_apply2(const void* y, const float* scale, const float* shift, const void* y2, const float* scale2,
-                          const float* shift2, void* out, long long rows, int C, int relu, hipStream_t s) {
+                          const float* shift2, void* out, void* bits, long long rows, int C, int relu, hipStream_t s) {
     if (C % 8 != 0 || C / 8 > 256 || 256 % (C / 8) != 0) return -1;
     long long nvec = rows * (C / 8);
     hipLaunchKernelGGL(bn_apply2_kernel, dim3(ew_grid(nvec, 4)), dim3(256), 0, s, (const bf16*)y, scale, shift,
-                       (const bf16*)y2, scale2, shift2, (bf16*)out, nvec, C / 8, relu);
+                       (const bf16*)y2, scale2, shift2, (bf16*)out, (unsigned char*)bits, nvec, C / 8, relu);
     return pdt_launch_status();
 }
 

@@ -39,8 +39,8 @@ def _sig(fn_name: str, *argtypes) -> None:
 
 
 _sig("pdt_sgd_step", _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _i, _vp)
-_sig("pdt_bn_apply", _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp)
-_sig("pdt_bn_apply2", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp)
+_sig("pdt_bn_apply", _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp)
+_sig("pdt_bn_apply2", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp)
 _sig("pdt_bn_bwd_elemt", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _ll, _i, _i, _vp)
 _sig("pdt_input_pad", _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _vp)
 _sig("pdt_maxpool_fwd", _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
@@ -71,9 +71,9 @@ _sig("pdt_car_set_timeout_ms", _vp, _i)
 _sig("pdt_car_allreduce", _vp, _vp, _i, _vp)
 _sig("pdt_car_query", _vp, _vp)
 _sig("pdt_car_destroy", _vp)
-_sig("pdt_conv_igemm", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+_sig("pdt_conv_igemm", _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
      _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp)
-_sig("pdt_conv_igemm_bstats", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+_sig("pdt_conv_igemm_bstats", _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i,
      _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp)
 _sig("pdt_conv_wgrad", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp)
 
@@ -258,7 +258,8 @@ def _part(t, b0: int, b1: int):
 
 
 def _igemm(inp, wgt, out, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, ldo, wrow, taps: _Taps,
-           addend=None, mask=None, bias=None, stat_acc=None, stat_shift=None, tile: int = 0, bstat=None) -> None:
+           addend=None, mask=None, bias=None, stat_acc=None, stat_shift=None, tile: int = 0, bstat=None,
+           mask_bits: bool = False) -> None:
     parts = _batch_parts(inp.shape[0], inp.numel() * inp.element_size())
     if parts is not None:
         B = inp.shape[0]
@@ -268,16 +269,16 @@ def _igemm(inp, wgt, out, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0
             sub = None if bstat is None else (bstat[0], bstat[1][b0:b1], *bstat[2:])
             _igemm(inp[b0:b1], wgt, out[b0:b1], (M // B) * (b1 - b0), Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS,
                    oy0, ox0, N, ldo, wrow, taps, addend=_part(addend, b0, b1), mask=_part(mask, b0, b1), bias=bias,
-                   stat_acc=stat_acc, stat_shift=stat_shift, tile=tile, bstat=sub)
+                   stat_acc=stat_acc, stat_shift=stat_shift, tile=tile, bstat=sub, mask_bits=mask_bits)
         return
     if bstat is not None:        # (acc, y, mean, scale-or-None, shift-or-None): BN-backward sums of the consumer
         acc, by, bmean, bscale, bshift = bstat
-        rc = _lib.pdt_conv_igemm_bstats(_p(inp), _p(wgt), _p(out), _p(addend), _p(mask), _p(acc), _p(by), _p(bmean),
+        rc = _lib.pdt_conv_igemm_bstats(_p(inp), _p(wgt), _p(out), _p(addend), _p(mask), int(mask_bits), _p(acc), _p(by), _p(bmean),
                                         _p(bscale), _p(bshift), M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0,
                                         ox0, N, ldo, wrow, taps.T, taps.offy, taps.offx, taps.widx, tile, _stream())
         _check(rc, "pdt_conv_igemm_bstats")
         return
-    rc = _lib.pdt_conv_igemm(_p(inp), _p(wgt), _p(out), _p(addend), _p(mask), _p(bias), _p(stat_acc), _p(stat_shift),
+    rc = _lib.pdt_conv_igemm(_p(inp), _p(wgt), _p(out), _p(addend), _p(mask), int(mask_bits), _p(bias), _p(stat_acc), _p(stat_shift),
                              M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, ldo, wrow, taps.T,
                              taps.offy, taps.offx, taps.widx, tile, _stream())
     _check(rc, "pdt_conv_igemm")
@@ -473,7 +474,7 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pa
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R: int, S: int, stride: int, pad: int,
                addend: Optional[torch.Tensor] = None, relu_mask: Optional[torch.Tensor] = None, tile: int = 0,
-               bwd_stats=None, out: Optional[torch.Tensor] = None):
+               bwd_stats=None, out: Optional[torch.Tensor] = None, relu_bits: Optional[torch.Tensor] = None):
     """``bwd_stats = (y, mean, scale, shift, mask_mode)`` of the BatchNorm layer that consumes the
     result ``g``: the epilogue also accumulates that layer's backward sums (what
     :func:`bn_bwd_reduce` would compute from ``g`` and ``y`` in a pass of its own); pass
@@ -487,7 +488,11 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
     if addend is not None:
         addend = _bf16c(addend, "conv_dgrad addend")
     mask_src = None
-    if relu_mask is not None:
+    bits = relu_bits is not None
+    if bits:            # packed ReLU mask of the tensor the gradient belongs to (see bn_apply bits_out)
+        _check_bits(relu_bits, (B, Hi, Wi, Ci), "conv_dgrad relu_bits")
+        mask_src = relu_bits
+    elif relu_mask is not None:
         mask_src = _bf16c(relu_mask, "conv_dgrad relu_mask")
     if tile == 0 and R == S and Hi == Wi:
         tile = _tile_hint("dgrad", B, Ci, Co, R, stride, Hi)
@@ -502,7 +507,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
                  bshift if recompute else None)
     if stride == 1:
         _igemm(dy, wt, dx, B * Hi * Wi, Ho, Wo, Co, Co, Hi, Wi, 1, Hi, Wi, 1, 0, 0, Ci, Ci, R * S * Co,
-               _dgrad_taps(R, S, pad, 1, 0, 0), addend=addend, mask=mask_src, tile=tile, bstat=bstat)
+               _dgrad_taps(R, S, pad, 1, 0, 0), addend=addend, mask=mask_src, tile=tile, bstat=bstat, mask_bits=bits)
         return dx
     for ph in range(stride):
         for pw in range(stride):
@@ -511,7 +516,8 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
             if Hg <= 0 or Wg <= 0:
                 continue
             _igemm(dy, wt, dx, B * Hg * Wg, Ho, Wo, Co, Co, Hg, Wg, 1, Hi, Wi, stride, ph, pw, Ci, Ci, R * S * Co,
-                   _dgrad_taps(R, S, pad, stride, ph, pw), addend=addend, mask=mask_src, tile=tile, bstat=bstat)
+                   _dgrad_taps(R, S, pad, stride, ph, pw), addend=addend, mask=mask_src, tile=tile, bstat=bstat,
+                   mask_bits=bits)
     return dx
 
 
@@ -583,19 +589,39 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps: float):
     return out[0], out[1]
 
 
-def bn_apply(y, scale, shift, residual, relu: bool, out: Optional[torch.Tensor] = None):
+relu_bits = True             # bn_apply/bn_apply2(bits_out=...) and conv_dgrad(relu_bits=...)
+
+
+def new_relu_bits(like: torch.Tensor) -> torch.Tensor:
+    """Destination for the packed ReLU mask of a tensor shaped like ``like``: one byte per 8 channels."""
+    return torch.empty(*like.shape[:-1], like.shape[-1] // 8, dtype=torch.uint8, device=like.device)
+
+
+def _check_bits(bits, shape, what: str) -> None:
+    want = (*shape[:-1], shape[-1] // 8)
+    if bits.dtype != torch.uint8 or tuple(bits.shape) != want or not bits.is_contiguous() or not bits.is_cuda:
+        raise ValueError(f"{what}: expected a contiguous uint8 GPU tensor of shape {want}")
+
+
+def bn_apply(y, scale, shift, residual, relu: bool, out: Optional[torch.Tensor] = None,
+             bits_out: Optional[torch.Tensor] = None):
+    """``bits_out``: also receives ``[out > 0]`` packed one byte per 8 channels -- what the ReLU
+    backward of this tensor needs, at 1/16 of the tensor's size."""
     y = _bf16c(y, "bn_apply y")
     C = y.shape[-1]
     out = _out_like(out, y.shape, y.device, "bn_apply")
     if residual is not None:
         residual = _bf16c(residual, "bn_apply residual")
-    rc = _lib.pdt_bn_apply(_p(y), _p(scale), _p(shift), _p(residual), _p(out), y.numel() // C, C, int(bool(relu)),
-                           _stream())
+    if bits_out is not None:
+        _check_bits(bits_out, y.shape, "bn_apply bits_out")
+    rc = _lib.pdt_bn_apply(_p(y), _p(scale), _p(shift), _p(residual), _p(out), _p(bits_out), y.numel() // C, C,
+                           int(bool(relu)), _stream())
     _check(rc, "pdt_bn_apply")
     return out
 
 
-def bn_apply2(y, scale, shift, y2, scale2, shift2, relu: bool, out: Optional[torch.Tensor] = None):
+def bn_apply2(y, scale, shift, y2, scale2, shift2, relu: bool, out: Optional[torch.Tensor] = None,
+              bits_out: Optional[torch.Tensor] = None):
     """``relu(y*scale + shift + y2*scale2 + shift2)``: main path and projection shortcut of a block
     normalised, added and activated in one pass."""
     y = _bf16c(y, "bn_apply2 y")
@@ -604,8 +630,10 @@ def bn_apply2(y, scale, shift, y2, scale2, shift2, relu: bool, out: Optional[tor
         raise ValueError("bn_apply2: the two tensors must have one shape")
     C = y.shape[-1]
     out = _out_like(out, y.shape, y.device, "bn_apply2")
-    rc = _lib.pdt_bn_apply2(_p(y), _p(scale), _p(shift), _p(y2), _p(scale2), _p(shift2), _p(out), y.numel() // C, C,
-                            int(bool(relu)), _stream())
+    if bits_out is not None:
+        _check_bits(bits_out, y.shape, "bn_apply2 bits_out")
+    rc = _lib.pdt_bn_apply2(_p(y), _p(scale), _p(shift), _p(y2), _p(scale2), _p(shift2), _p(out), _p(bits_out),
+                            y.numel() // C, C, int(bool(relu)), _stream())
     _check(rc, "pdt_bn_apply2")
     return out
 

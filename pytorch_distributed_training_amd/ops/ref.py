@@ -101,8 +101,10 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pa
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: Optional[torch.Tensor], in_shape, R: int, S: int,
                stride: int, pad: int, addend: Optional[torch.Tensor] = None,
-               relu_mask: Optional[torch.Tensor] = None, **_) -> torch.Tensor:
+               relu_mask: Optional[torch.Tensor] = None, relu_bits: Optional[torch.Tensor] = None,
+               **_) -> torch.Tensor:
     """``dx = (conv_transpose(dy, w) [+ addend]) [* (relu_mask > 0)]`` ; ``in_shape = (B, Hi, Wi, Ci)``.
+    ``relu_bits``: the same mask in packed form (see :func:`bn_apply`).
 
     ``addend`` accumulates the other gradient path of a residual block; ``relu_mask`` (the
     post-ReLU tensor this gradient belongs to) applies that ReLU's backward right here, so the
@@ -114,7 +116,9 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: Optional[torch.Tensor], in
     dx = dx.to(dy.dtype)
     if addend is not None:
         dx = (dx.float() + addend.float()).to(dy.dtype)
-    if relu_mask is not None:
+    if relu_bits is not None:
+        dx = dx * _unpack_bits(relu_bits)
+    elif relu_mask is not None:
         dx = dx * (relu_mask > 0)
     return dx
 
@@ -167,14 +171,39 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps: float):
     return scale, beta - running_mean * scale
 
 
+relu_bits = True             # bn_apply/bn_apply2(bits_out=...) and conv_dgrad(relu_bits=...)
+_BIT_WEIGHTS = (1, 2, 4, 8, 16, 32, 64, 128)
+
+
+def new_relu_bits(like: torch.Tensor) -> torch.Tensor:
+    """Destination for the packed ReLU mask of a tensor shaped like ``like``: one byte per 8 channels."""
+    return torch.empty(*like.shape[:-1], like.shape[-1] // 8, dtype=torch.uint8, device=like.device)
+
+
+def _pack_bits(out: torch.Tensor, bits_out: torch.Tensor) -> None:
+    w = torch.tensor(_BIT_WEIGHTS, dtype=torch.int32, device=out.device)
+    on = (out > 0).to(torch.int32).reshape(*out.shape[:-1], out.shape[-1] // 8, 8)
+    bits_out.copy_((on * w).sum(-1).to(torch.uint8))
+
+
+def _unpack_bits(bits: torch.Tensor) -> torch.Tensor:
+    w = torch.tensor(_BIT_WEIGHTS, dtype=torch.int32, device=bits.device)
+    on = (bits.to(torch.int32).unsqueeze(-1) & w) != 0
+    return on.reshape(*bits.shape[:-1], bits.shape[-1] * 8)
+
+
 def bn_apply(y: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, residual: Optional[torch.Tensor],
-             relu: bool) -> torch.Tensor:
+             relu: bool, bits_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``bits_out``: also receives ``[out > 0]``, bit k of byte j = channel ``8j + k``."""
     out = y.float() * scale + shift
     if residual is not None:
         out = out + residual.float()
     if relu:
         out = torch.relu(out)
-    return out.to(y.dtype)
+    out = out.to(y.dtype)
+    if bits_out is not None:
+        _pack_bits(out, bits_out)
+    return out
 
 
 def _masked(g, y32, scale, shift, mask_src, mask_mode):
@@ -186,13 +215,16 @@ def _masked(g, y32, scale, shift, mask_src, mask_mode):
     return dy
 
 
-def bn_apply2(y, scale, shift, y2, scale2, shift2, relu: bool):
+def bn_apply2(y, scale, shift, y2, scale2, shift2, relu: bool, bits_out: Optional[torch.Tensor] = None):
     """``relu(y*scale + shift + y2*scale2 + shift2)`` -- a block's main path and its projection
     shortcut normalised, added and activated in one pass (one rounding to the compute dtype)."""
     out = y.float() * scale + shift + y2.float() * scale2 + shift2
     if relu:
         out = torch.relu(out)
-    return out.to(y.dtype)
+    out = out.to(y.dtype)
+    if bits_out is not None:
+        _pack_bits(out, bits_out)
+    return out
 
 
 def bn_bwd_reduce(g, y, mean, invstd, scale, shift, mask_src, mask_mode: int,

@@ -309,6 +309,38 @@ def test_pooling(hip, device, B, H, C):
     assert rel_err(hip.avgpool_bwd(dp, H, H, mk), ref.avgpool_bwd(dp, H, H, mk)) < 1e-2
 
 
+@pytest.mark.parametrize("C,H,stride,k", [(256, 14, 1, 1), (128, 16, 2, 3), (64, 9, 1, 3)])
+def test_packed_relu_mask_roundtrip(hip, device, C, H, stride, k):
+    """bn_apply / bn_apply2 write the ReLU mask of their output as bits; conv_dgrad applies it."""
+    torch.manual_seed(C + H)
+    B = 3
+    y, res = rnd(B, H, H, C, device=device), rnd(B, H, H, C, device=device)
+    scale, shift = torch.rand(C, device=device) + 0.5, torch.randn(C, device=device) * 0.3
+    bits = hip.new_relu_bits(y)
+    out = hip.bn_apply(y, scale, shift, res, True, bits_out=bits)
+    assert torch.equal(out, hip.bn_apply(y, scale, shift, res, True))
+    want = torch.empty_like(bits)
+    ref._pack_bits(out, want)
+    assert torch.equal(bits, want) and torch.equal(ref._unpack_bits(bits), out > 0)
+    bits2 = hip.new_relu_bits(y)
+    out2 = hip.bn_apply2(y, scale, shift, res, scale * 0.5, shift, True, bits_out=bits2)
+    ref._pack_bits(out2, want)
+    assert torch.equal(bits2, want)
+    # data gradient masked by the bits == masked by the tensor
+    Co = 64
+    w = rnd(Co, k, k, C, device=device, scale=0.05)
+    wt = torch.empty(C, k, k, Co, dtype=torch.bfloat16, device=device)
+    hip.transpose_weights(w, wt)
+    pad = k // 2
+    Ho = (H + 2 * pad - k) // stride + 1
+    dy = rnd(B, Ho, Ho, Co, device=device)
+    a = hip.conv_dgrad(dy, w, wt, tuple(out.shape), k, k, stride, pad, addend=res, relu_mask=out)
+    b = hip.conv_dgrad(dy, w, wt, tuple(out.shape), k, k, stride, pad, addend=res, relu_bits=bits)
+    assert torch.equal(a, b)
+    c = ref.conv_dgrad(dy, w, None, tuple(out.shape), k, k, stride, pad, addend=res, relu_bits=bits)
+    assert rel_err(b, c) < 1.5e-2
+
+
 @pytest.mark.parametrize("B,H,C", [(2, 112, 64), (3, 30, 64), (1, 9, 128)])
 def test_bn_backward_through_fused_relu_maxpool(hip, device, B, H, C):
     """BatchNorm-backward passes fed with the POOLED gradient + winner indices against the
