@@ -84,7 +84,7 @@ __device__ __forceinline__ int swz_chunk(int row, int chunk) {
 }
 
 template <int BM, int BN, int BK, int WM, int WN, bool BSTAT>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256, ((BM * BN == 128 * 64 && !BSTAT) ? 3 : 2)) void igemm_kernel(const IgemmParams p) {
     constexpr int CH = BK / 8;            // 16-byte chunks per LDS row
     constexpr int RPP = 256 / CH;         // rows covered by one pass of the 256 threads
     constexpr int A_IT = BM / RPP;
@@ -382,58 +382,127 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
             }
         }
         if (n < p.ldo) {                         // ldo is a multiple of 8 (checked by the launcher)
-            for (int row = tid / NV; row < rows_valid; row += TR) {
-                long long m = m0 + row;
-                long long orow;
-                if (p.simple_out) {
-                    orow = m;
-                } else {
-                    unsigned mu = (unsigned)m;
-                    int b = (int)(mu / (unsigned)HgWg);
-                    int rem = (int)(mu - (unsigned)b * (unsigned)HgWg);
-                    int y = (int)((unsigned)rem / (unsigned)p.Wg), x = rem - y * p.Wg;
-                    orow = ((long long)b * p.Ho + (y * p.OS + p.oy0)) * p.Wo + (x * p.OS + p.ox0);
-                }
-                bf16x8 ov = *reinterpret_cast<const bf16x8*>(Cs + row * CLD + cv * 8);
-                long long o = orow * p.ldo + n;
-                if (p.addend) {
-                    bf16x8 a = ld_bf16x8(p.addend + o);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) ov[k] = f2bf(bf2f(ov[k]) + bf2f(a[k]));
-                }
-                bf16x8 yv;
-                if (bwd_stats) yv = ld_bf16x8(p.bstat_y + o);
-                if (p.mask) {
-                    if (p.mask_bits) {
-                        unsigned mb = reinterpret_cast<const unsigned char*>(p.mask)[o >> 3];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) ov[k] = ((mb >> k) & 1u) ? ov[k] : f2bf(0.0f);
+            if constexpr (!BSTAT) {
+                // plain instantiations (forward, data gradients without fused statistics of the
+                // consumer): at most two global loads per row, one row per trip
+                for (int row = tid / NV; row < rows_valid; row += TR) {
+                    long long m = m0 + row;
+                    long long orow;
+                    if (p.simple_out) {
+                        orow = m;
                     } else {
-                        bf16x8 mk = ld_bf16x8(p.mask + o);
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) ov[k] = bf2f(mk[k]) > 0.0f ? ov[k] : f2bf(0.0f);
+                        unsigned mu = (unsigned)m;
+                        int b = (int)(mu / (unsigned)HgWg);
+                        int rem = (int)(mu - (unsigned)b * (unsigned)HgWg);
+                        int y = (int)((unsigned)rem / (unsigned)p.Wg), x = rem - y * p.Wg;
+                        orow = ((long long)b * p.Ho + (y * p.OS + p.oy0)) * p.Wo + (x * p.OS + p.ox0);
                     }
-                }
-                st_bf16x8(p.out + o, ov);
-                if (bwd_stats) {
+                    bf16x8 ov = *reinterpret_cast<const bf16x8*>(Cs + row * CLD + cv * 8);
+                    long long o = orow * p.ldo + n;
+                    if (p.addend) {
+                        bf16x8 a = ld_bf16x8(p.addend + o);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        float yy = bf2f(yv[k]);
-                        float dy = bf2f(ov[k]);
-                        if (BSTAT) {
-                            if (bwd_mask) dy = (yy * msc[k] + msh[k]) > 0.0f ? dy : 0.0f;
+                        for (int k = 0; k < 8; ++k) ov[k] = f2bf(bf2f(ov[k]) + bf2f(a[k]));
+                    }
+                    if (p.mask) {
+                        if (p.mask_bits) {
+                            unsigned mb = reinterpret_cast<const unsigned char*>(p.mask)[o >> 3];
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) ov[k] = ((mb >> k) & 1u) ? ov[k] : f2bf(0.0f);
+                        } else {
+                            bf16x8 mk = ld_bf16x8(p.mask + o);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) ov[k] = bf2f(mk[k]) > 0.0f ? ov[k] : f2bf(0.0f);
                         }
-                        s0[k] += dy;
-                        s1[k] += dy * (yy - sh[k]);
                     }
-                } else if (want_stats) {
+                    st_bf16x8(p.out + o, ov);
+                    if (want_stats) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        float d = bf2f(ov[k]) - sh[k];
-                        s0[k] += d;
-                        s1[k] += d * d;
+                        for (int k = 0; k < 8; ++k) {
+                            float d = bf2f(ov[k]) - sh[k];
+                            s0[k] += d;
+                            s1[k] += d * d;
+                        }
                     }
                 }
+            } else {
+            // Backward-statistics instantiations: EU rows per trip, all their global loads (addend,
+            // mask, BatchNorm input) issued before the first result is used, so a thread keeps EU
+            // times the bytes in flight -- the epilogue of the 1x1 data gradients moves 3-4x the
+            // bytes of their main loop (measured: -0.95 ms per ResNet-50 step at batch 512 with 2
+            // rows; 3 rows spill registers and lose 4 ms).
+            constexpr int EU = 2;
+            for (int row0 = tid / NV; row0 < rows_valid; row0 += EU * TR) {
+                long long oo[EU];
+                bool live[EU];
+                bf16x8 ov[EU], av[EU], yv[EU], mk[EU];
+                unsigned mb[EU];
+#pragma unroll
+                for (int e = 0; e < EU; ++e) {
+                    int row = row0 + e * TR;
+                    live[e] = row < rows_valid;
+                    if (!live[e]) row = row0;               // harmless duplicate of the first row
+                    long long m = m0 + row;
+                    long long orow;
+                    if (p.simple_out) {
+                        orow = m;
+                    } else {
+                        unsigned mu = (unsigned)m;
+                        int b = (int)(mu / (unsigned)HgWg);
+                        int rem = (int)(mu - (unsigned)b * (unsigned)HgWg);
+                        int y = (int)((unsigned)rem / (unsigned)p.Wg), x = rem - y * p.Wg;
+                        orow = ((long long)b * p.Ho + (y * p.OS + p.oy0)) * p.Wo + (x * p.OS + p.ox0);
+                    }
+                    oo[e] = orow * p.ldo + n;
+                    if (p.addend) av[e] = ld_bf16x8(p.addend + oo[e]);
+                    if (bwd_stats) yv[e] = ld_bf16x8(p.bstat_y + oo[e]);
+                    if (p.mask) {
+                        if (p.mask_bits) mb[e] = reinterpret_cast<const unsigned char*>(p.mask)[oo[e] >> 3];
+                        else mk[e] = ld_bf16x8(p.mask + oo[e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < EU; ++e) {
+                    // the tile row comes out of LDS only now: it would occupy registers for nothing
+                    // while the global loads above are in flight
+                    const int row = live[e] ? row0 + e * TR : row0;
+                    ov[e] = *reinterpret_cast<const bf16x8*>(Cs + row * CLD + cv * 8);
+                    if (p.addend) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) ov[e][k] = f2bf(bf2f(ov[e][k]) + bf2f(av[e][k]));
+                    }
+                    if (p.mask) {
+                        if (p.mask_bits) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) ov[e][k] = ((mb[e] >> k) & 1u) ? ov[e][k] : f2bf(0.0f);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) ov[e][k] = bf2f(mk[e][k]) > 0.0f ? ov[e][k] : f2bf(0.0f);
+                        }
+                    }
+                    if (!live[e]) continue;
+                    st_bf16x8(p.out + oo[e], ov[e]);
+                    if (bwd_stats) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            float yy = bf2f(yv[e][k]);
+                            float dy = bf2f(ov[e][k]);
+                            if (BSTAT) {
+                                if (bwd_mask) dy = (yy * msc[k] + msh[k]) > 0.0f ? dy : 0.0f;
+                            }
+                            s0[k] += dy;
+                            s1[k] += dy * (yy - sh[k]);
+                        }
+                    } else if (want_stats) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            float d = bf2f(ov[e][k]) - sh[k];
+                            s0[k] += d;
+                            s1[k] += d * d;
+                        }
+                    }
+                }
+            }
             }
         }
         // The partial sums stay in registers while this block's next tile covers the same
