@@ -162,6 +162,7 @@ class NativeResNet:
         # ReLU backward of a block output from a packed bit mask written by the pass that produced
         # the tensor, instead of re-reading the tensor for its sign in the data-gradient epilogue.
         self._relu_bits = bool(getattr(ops, "relu_bits", False)) and os.environ.get("PDT_RELU_BITS", "1") == "1"
+        self._relu_bits_only = bool(getattr(ops, "bwd_stats_need_bits", False))
         # Step replay (see .graphs): the second step of a batch signature is recorded, later ones
         # replay the record.  "list": a command list of the backend's own launches (default);
         # "graph": HIP graphs separated by host actions.  PDT_HIP_GRAPHS: 0 = off, 1 = on,
@@ -616,10 +617,13 @@ class NativeResNet:
         return {"bwd_stats": (ctx.y, ctx.mean, ctx.scale, ctx.shift, mask_mode)}
 
     def _block_backward(self, b: BlockSpec, g: torch.Tensor, g_prereduced: bool = False,
-                        prev_last: Optional[ConvBNSpec] = None) -> torch.Tensor:
+                        prev_last: Optional[ConvBNSpec] = None) -> Tuple[torch.Tensor, bool]:
         """``g``: gradient w.r.t. the block's pre-ReLU sum, i.e. ALREADY multiplied by the mask of
         the block's output ReLU (the producer of ``g`` fuses that).  Returns the gradient w.r.t.
         the block input, likewise already masked by the input tensor's own ReLU.
+
+        Second result: whether that final kernel also accumulated the backward sums of
+        ``prev_last``'s BatchNorm (what the caller passes as the next ``g_prereduced``).
 
         ``g_prereduced``: the kernel that produced ``g`` also accumulated the backward sums of this
         block's last BatchNorm.  ``prev_last``: the last unit of the block that produced this
@@ -660,9 +664,11 @@ class NativeResNet:
         # where a zero means the whole pooling window was zero): apply its ReLU backward here.
         bits = getattr(x_block, "_pdt_relu_bits", None)
         mkw = {"relu_bits": bits} if bits is not None else {"relu_mask": x_block}
-        return ops.conv_dgrad(dy_first, P.compute(key0), self._wt_view(key0), tuple(x_block.shape),
-                              u0.ksize, u0.ksize, u0.stride, u0.pad, addend=other, **mkw,
-                              **(self._bstats(prev_last, MASK_NONE) or {}))
+        # the fused backward sums of the previous block's last BatchNorm need the packed mask
+        skw = (self._bstats(prev_last, MASK_NONE) or {}) if (bits is not None or not self._relu_bits_only) else {}
+        g_in = ops.conv_dgrad(dy_first, P.compute(key0), self._wt_view(key0), tuple(x_block.shape),
+                              u0.ksize, u0.ksize, u0.stride, u0.pad, addend=other, **mkw, **skw)
+        return g_in, bool(skw)
 
     def backward(self, dlogits: torch.Tensor) -> None:
         """Back-propagate ``dlogits``; gradients accumulate into the flat gradient buffer."""
@@ -680,8 +686,7 @@ class NativeResNet:
             pre = False
             for j in range(len(blocks) - 1, -1, -1):
                 prev_last = blocks[j - 1].units[-1] if j > 0 else None
-                g = self._block_backward(blocks[j], g, pre, prev_last)
-                pre = prev_last is not None and self._fused_bwd_stats
+                g, pre = self._block_backward(blocks[j], g, pre, prev_last)
             stem = self.spec.stem
             ctx = self._ctx.pop(stem.bn)
             pool_idx, stem_shape = self._saved.pop("pool_idx"), self._saved.pop("stem_shape")

@@ -431,11 +431,13 @@ __global__ __launch_bounds__(256, ((BM * BN == 128 * 64 && !BSTAT) ? 3 : 2)) voi
             // times the bytes in flight -- the epilogue of the 1x1 data gradients moves 3-4x the
             // bytes of their main loop (measured: -0.95 ms per ResNet-50 step at batch 512 with 2
             // rows; 3 rows spill registers and lose 4 ms).
+            // (These variants read the ReLU mask in packed form only: the tensor form costs 8 more
+            // registers, which the 128x128 tile does not have.)
             constexpr int EU = 2;
             for (int row0 = tid / NV; row0 < rows_valid; row0 += EU * TR) {
                 long long oo[EU];
                 bool live[EU];
-                bf16x8 ov[EU], av[EU], yv[EU], mk[EU];
+                bf16x8 ov[EU], av[EU], yv[EU];
                 unsigned mb[EU];
 #pragma unroll
                 for (int e = 0; e < EU; ++e) {
@@ -456,10 +458,7 @@ __global__ __launch_bounds__(256, ((BM * BN == 128 * 64 && !BSTAT) ? 3 : 2)) voi
                     oo[e] = orow * p.ldo + n;
                     if (p.addend) av[e] = ld_bf16x8(p.addend + oo[e]);
                     if (bwd_stats) yv[e] = ld_bf16x8(p.bstat_y + oo[e]);
-                    if (p.mask) {
-                        if (p.mask_bits) mb[e] = reinterpret_cast<const unsigned char*>(p.mask)[oo[e] >> 3];
-                        else mk[e] = ld_bf16x8(p.mask + oo[e]);
-                    }
+                    if (p.mask) mb[e] = reinterpret_cast<const unsigned char*>(p.mask)[oo[e] >> 3];
                 }
 #pragma unroll
                 for (int e = 0; e < EU; ++e) {
@@ -472,13 +471,8 @@ __global__ __launch_bounds__(256, ((BM * BN == 128 * 64 && !BSTAT) ? 3 : 2)) voi
                         for (int k = 0; k < 8; ++k) ov[e][k] = f2bf(bf2f(ov[e][k]) + bf2f(av[e][k]));
                     }
                     if (p.mask) {
-                        if (p.mask_bits) {
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) ov[e][k] = ((mb[e] >> k) & 1u) ? ov[e][k] : f2bf(0.0f);
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) ov[e][k] = bf2f(mk[e][k]) > 0.0f ? ov[e][k] : f2bf(0.0f);
-                        }
+                        for (int k = 0; k < 8; ++k) ov[e][k] = ((mb[e] >> k) & 1u) ? ov[e][k] : f2bf(0.0f);
                     }
                     if (!live[e]) continue;
                     st_bf16x8(p.out + oo[e], ov[e]);
@@ -599,6 +593,7 @@ static int conv_igemm_impl(const void* in, const void* wgt, void* out, const voi
     p.N = N; p.ldo = ldo; p.wrow = wrow; p.T = T;
     p.mask_bits = (mask && mask_bits) ? 1 : 0;
     if (p.mask_bits && ldo != N) return -8;        // the bit image is indexed like a dense [rows][N] tensor
+    if (bstat_y && mask && !mask_bits) return -9;  // the backward-statistics variants take the mask as bits only
     p.simple_out = (OS == 1 && oy0 == 0 && ox0 == 0 && Hg == Ho && Wg == Wo) ? 1 : 0;
     for (int i = 0; i < T; ++i)
         p.taps[i] = ((int)offy[i] & 0xff) | (((int)offx[i] & 0xff) << 8) | ((int)widx[i] << 16);

@@ -505,6 +505,8 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
         recompute = bmode == MASK_RECOMPUTE
         bstat = (_accumulator(dy.device, Ci, "bwd"), by, bmean, bscale if recompute else None,
                  bshift if recompute else None)
+    if bstat is not None and mask_src is not None and not bits:
+        raise ValueError("conv_dgrad: with bwd_stats the ReLU mask must be given in packed form (relu_bits)")
     if stride == 1:
         _igemm(dy, wt, dx, B * Hi * Wi, Ho, Wo, Co, Co, Hi, Wi, 1, Hi, Wi, 1, 0, 0, Ci, Ci, R * S * Co,
                _dgrad_taps(R, S, pad, 1, 0, 0), addend=addend, mask=mask_src, tile=tile, bstat=bstat, mask_bits=bits)
@@ -590,6 +592,7 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps: float):
 
 
 relu_bits = True             # bn_apply/bn_apply2(bits_out=...) and conv_dgrad(relu_bits=...)
+bwd_stats_need_bits = True   # conv_dgrad(bwd_stats=...) takes its ReLU mask in packed form only
 
 
 def new_relu_bits(like: torch.Tensor) -> torch.Tensor:

@@ -100,12 +100,14 @@ def test_conv_launches_split_over_the_batch(hip, device, monkeypatch, k, stride,
     wt = torch.empty(Ci, k, k, Co, dtype=torch.bfloat16, device=device)
     hip.transpose_weights(w, wt)
     shift = torch.zeros(Co, device=device)
+    bits = hip.new_relu_bits(x)
+    ref._pack_bits(x, bits)
 
     def run():
         y, mom = hip.conv_fprop(x, w, k, k, stride, pad, shift)
         dy = (y.float() * 0.5 + 0.1).to(torch.bfloat16)
         mean = torch.randn(Ci, device=device) * 0.1
-        dx = hip.conv_dgrad(dy, w, wt, tuple(x.shape), k, k, stride, pad, addend=x, relu_mask=x,
+        dx = hip.conv_dgrad(dy, w, wt, tuple(x.shape), k, k, stride, pad, addend=x, relu_bits=bits,
                             bwd_stats=(x, mean, None, None, ref.MASK_NONE))
         sums = hip.bn_bwd_reduce(dx, x, mean, torch.ones(Ci, device=device), None, None, None, ref.MASK_NONE,
                                  prereduced=True)
@@ -339,6 +341,15 @@ def test_packed_relu_mask_roundtrip(hip, device, C, H, stride, k):
     assert torch.equal(a, b)
     c = ref.conv_dgrad(dy, w, None, tuple(out.shape), k, k, stride, pad, addend=res, relu_bits=bits)
     assert rel_err(b, c) < 1.5e-2
+    # with fused backward statistics the mask is accepted in packed form only
+    mean = torch.zeros(C, device=device)
+    d = hip.conv_dgrad(dy, w, wt, tuple(out.shape), k, k, stride, pad, addend=res, relu_bits=bits,
+                       bwd_stats=(y, mean, None, None, ref.MASK_NONE))
+    hip.bn_bwd_reduce(d, y, mean, torch.ones(C, device=device), None, None, None, ref.MASK_NONE, prereduced=True)
+    assert torch.equal(d, a)
+    with pytest.raises(ValueError):
+        hip.conv_dgrad(dy, w, wt, tuple(out.shape), k, k, stride, pad, addend=res, relu_mask=out,
+                       bwd_stats=(y, mean, None, None, ref.MASK_NONE))
 
 
 @pytest.mark.parametrize("B,H,C", [(2, 112, 64), (3, 30, 64), (1, 9, 128)])
