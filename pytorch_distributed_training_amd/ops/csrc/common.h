@@ -68,6 +68,12 @@ __device__ __forceinline__ void pool3x3s2_grad8(const bf16* __restrict__ dout, c
     }
 }
 
+// Streaming store: a large result that the next kernel cannot find in cache anyway goes out
+// without claiming cache lines.
+__device__ __forceinline__ void st_stream_bf16x8(bf16* p, bf16x8 v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p));
+}
+
 __device__ __forceinline__ bf16x8 zero_bf16x8() {
     bf16x8 z;
 #pragma unroll

@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256, ((BM * BN == 128 * 64 && !BSTAT) ? 3 : 2)) voi
                             for (int k = 0; k < 8; ++k) ov[k] = bf2f(mk[k]) > 0.0f ? ov[k] : f2bf(0.0f);
                         }
                     }
-                    st_bf16x8(p.out + o, ov);
+                    st_stream_bf16x8(p.out + o, ov);
                     if (want_stats) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256, ((BM * BN == 128 * 64 && !BSTAT) ? 3 : 2)) voi
                         for (int k = 0; k < 8; ++k) ov[e][k] = ((mb[e] >> k) & 1u) ? ov[e][k] : f2bf(0.0f);
                     }
                     if (!live[e]) continue;
-                    st_bf16x8(p.out + oo[e], ov[e]);
+                    st_stream_bf16x8(p.out + oo[e], ov[e]);
                     if (bwd_stats) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void bn_bwd_elemt_kernel(const bf16* __restric
             if (MODE == MASK_RECOMPUTE) dy = (yy * A[k] + sh[k]) > 0.0f ? dy : 0.0f;
             o[k] = f2bf(dy * A[k] + yy * Bc[k] + Cc[k]);
         }
-        st_bf16x8(dx + i * 8, o);
+        st_stream_bf16x8(dx + i * 8, o);
     }
 }
 
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_elemt_kernel(
             float dy = (yy * A[k] + sh[k]) > 0.0f ? g[k] : 0.0f;
             o[k] = f2bf(dy * A[k] + yy * Bc[k] + Cc[k]);
         }
-        st_bf16x8(dx + i * 8, o);
+        st_stream_bf16x8(dx + i * 8, o);
     }
 }
 
