@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256, ((BM * BN == 128 * 64 && !BSTAT) ? 3 : 2)) voi
                         orow = ((long long)b * p.Ho + (y * p.OS + p.oy0)) * p.Wo + (x * p.OS + p.ox0);
                     }
                     oo[e] = orow * p.ldo + n;
-                    if (p.addend) av[e] = ld_bf16x8(p.addend + oo[e]);
+                    if (p.addend) av[e] = ld_stream_bf16x8(p.addend + oo[e]);      // last use of the incoming gradient
                     if (bwd_stats) yv[e] = ld_bf16x8(p.bstat_y + oo[e]);
                     if (p.mask) mb[e] = reinterpret_cast<const unsigned char*>(p.mask)[oo[e] >> 3];
                 }
