@@ -213,6 +213,185 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         }
 }
 
+// Variant for layers with a narrow gathered operand and several taps (the ResNet stem on its packed
+// NHWC4 image: 7 taps of 32 values): one workgroup owns ALL taps of its (Cout tile, pixel slice), so a
+// dY tile is loaded once per K step and multiplied against TAPS gathered X tiles -- with one tap per
+// workgroup the same dY tile crosses L2 -> LDS seven times and that traffic is all the kernel does.
+// Single LDS stage (A + TAPS x B stays under 64 KB, three workgroups per CU cover each other's barriers),
+// the next step's tiles wait in registers.
+template <int BMO, int BNC, int WM, int WN, int TAPS>
+__global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(const WgradParams p) {
+    constexpr int RSA = (BMO + 16) * 2;
+    constexpr int RSB = (BNC + 16) * 2;
+    constexpr int A_BYTES = BKP * RSA, B_BYTES = BKP * RSB;
+    constexpr int AV = BMO / 8, BV = BNC / 8;
+    constexpr int A_RPP = 256 / AV, B_RPP = 256 / BV;
+    constexpr int A_IT = (BKP + A_RPP - 1) / A_RPP, B_IT = (BKP + B_RPP - 1) / B_RPP;
+    constexpr int WTM = BMO / WM, WTN = BNC / WN;
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+    static_assert(A_BYTES + TAPS * B_BYTES <= 65536, "one LDS stage must fit the static limit");
+    static_assert(BKP % A_RPP == 0 && BKP % B_RPP == 0, "tile/thread mismatch");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + TAPS * B_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int n_ct = (p.N + BMO - 1) / BMO;
+    const int nwg = p.splitk * n_ct;
+    int wgid;
+    {
+        int orig = blockIdx.x;
+        int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int ct = wgid % n_ct;
+    const int split = wgid / n_ct;
+    const int co0 = ct * BMO;
+    int oy[TAPS], ox[TAPS], wi_tap[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) unpack_tap(p.taps[t], oy[t], ox[t], wi_tap[t]);
+
+    const long long r_begin = (long long)split * p.rows_per_split;
+    long long r_end = r_begin + p.rows_per_split;
+    if (r_end > p.M) r_end = p.M;
+    const int nk = r_begin < r_end ? (int)((r_end - r_begin + BKP - 1) / BKP) : 0;
+    if (nk == 0) return;
+
+    const int a_cv = tid % AV, a_row = tid / AV;
+    const int b_cv = tid % BV, b_row = tid / BV;
+    const bool a_col_ok = co0 + a_cv * 8 < p.N;
+    const bool b_col_ok = b_cv * 8 < p.Ci;
+    const int HgWg = p.Hg * p.Wg;
+
+    const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(p.dy, p.dy_bytes);
+    const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(p.in, p.in_bytes);
+    bf16x8 a_reg[A_IT], b_reg[TAPS][B_IT];
+    auto load_tiles = [&](long long r0) {
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            int row = a_row + j * A_RPP;
+            long long m = r0 + row;
+            bool ok = m < r_end && a_col_ok;
+            unsigned off = (unsigned)((unsigned)m * (unsigned)p.ldy + co0 + a_cv * 8) * 2u;
+            a_reg[j] = buf_ld_bf16x8(dy_rsrc, ok ? off : PDT_OOB_OFFSET);
+        }
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            int row = b_row + j * B_RPP;
+            long long m = r0 + row;
+            unsigned mu = m < r_end ? (unsigned)m : 0u;
+            int b = (int)(mu / (unsigned)HgWg);
+            int rem = (int)(mu - (unsigned)b * (unsigned)HgWg);
+            int y = (int)((unsigned)rem / (unsigned)p.Wg), x = rem - y * p.Wg;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                int iy = y * p.IS + oy[t], ix = x * p.IS + ox[t];
+                bool ok = m < r_end && b_col_ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                unsigned off = (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.pix_stride + b_cv * 8) * 2u;
+                b_reg[t][j] = buf_ld_bf16x8(in_rsrc, ok ? off : PDT_OOB_OFFSET);
+            }
+        }
+    };
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + A_BYTES;
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            int row = a_row + j * A_RPP;
+            *reinterpret_cast<bf16x8*>(As + row * RSA + a_cv * 16) = a_reg[j];
+        }
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int j = 0; j < B_IT; ++j) {
+                int row = b_row + j * B_RPP;
+                *reinterpret_cast<bf16x8*>(Bs + t * B_BYTES + row * RSB + b_cv * 16) = b_reg[t][j];
+            }
+    };
+
+    f32x4 acc[TAPS][MI][NI];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+    const int trow0 = 4 * g + q4;
+    const int tcol = 4 * pp;
+
+    load_tiles(r_begin);
+    for (int ks = 0; ks < nk; ++ks) {
+        store_tiles();
+        __syncthreads();
+        if (ks + 1 < nk) load_tiles(r_begin + (long long)(ks + 1) * BKP);
+#pragma unroll
+        for (int kk = 0; kk < BKP / 32; ++kk) {
+            bf16x8 af[MI];
+            const int r0 = kk * 32 + trow0, r1 = r0 + 16;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                int col = wm * WTM + i * 16 + tcol;
+                af[i] = tr_read_pair(As + r0 * RSA + col * 2, As + r1 * RSA + col * 2);
+            }
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                bf16x8 bfr[NI];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    int col = wn * WTN + j * 16 + tcol;
+                    const unsigned char* Bt = Bs + t * B_BYTES;
+                    bfr[j] = tr_read_pair(Bt + r0 * RSB + col * 2, Bt + r1 * RSB + col * 2);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[t][i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();          // every wave is done with this stage before it is overwritten
+    }
+
+    const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        const long long wofs = (long long)wi_tap[t] * p.Ci;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                int c = wn * WTN + j * 16 + frow;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int n = co0 + wm * WTM + i * 16 + fq * 4 + r;
+                    if (n < p.N && c < p.Ci) atomicAdd(p.dw + (long long)n * p.wrow + wofs + c, acc[t][i][j][r]);
+                }
+            }
+    }
+}
+
+template <int BMO, int BNC, int WM, int WN, int TAPS>
+static int launch_wgrad_taps(WgradParams& p, hipStream_t s, int target_blocks) {
+    if (p.T != TAPS || p.Ci > BNC) return -6;
+    int n_ct = (p.N + BMO - 1) / BMO;
+    long long max_split = (p.M + 2 * BKP - 1) / (2 * BKP);
+    long long split = (target_blocks + n_ct - 1) / n_ct;
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    long long rps = (p.M + split - 1) / split;
+    rps = (rps + BKP - 1) / BKP * BKP;
+    split = (p.M + rps - 1) / rps;
+    p.splitk = (int)split;
+    p.rows_per_split = rps;
+    long long nwg = (long long)n_ct * split;
+    if (nwg > 0x7fffffffLL) return -2;
+    hipLaunchKernelGGL((wgrad_taps_kernel<BMO, BNC, WM, WN, TAPS>), dim3((unsigned)nwg), dim3(256), 0, s, p);
+    return pdt_launch_status();
+}
+
 template <int BMO, int BNC, int WM, int WN>
 static int launch_wgrad(WgradParams& p, hipStream_t s, int target_blocks, long long atomic_budget_bytes) {
     int n_ct = (p.N + BMO - 1) / BMO;
@@ -240,7 +419,8 @@ static int launch_wgrad(WgradParams& p, hipStream_t s, int target_blocks, long l
     return pdt_launch_status();
 }
 
-// tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 64x32 (stem), 4 = 128x64
+// tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 64x32 (one tap per workgroup), 4 = 128x64,
+//       5 = 64x32 with all 7 taps per workgroup (the stem; auto picks it for T == 7, Ci <= 32)
 PDT_API int pdt_conv_wgrad(const void* dy, const void* in, float* dw, long long M, int Hi, int Wi, int pix_stride,
                            int Ci, int Hg, int Wg, int IS, int N, int ldy, int wrow, int T, const signed char* offy,
                            const signed char* offx, const unsigned short* widx, int tile, int target_blocks,
@@ -266,7 +446,7 @@ PDT_API int pdt_conv_wgrad(const void* dy, const void* in, float* dw, long long 
     if (target_blocks <= 0) target_blocks = 2048;
     long long budget = (long long)(atomic_budget_mb > 0 ? atomic_budget_mb : 24) << 20;
     if (tile == 0) {
-        if (Ci <= 32) tile = 3;
+        if (Ci <= 32) tile = (T == 7) ? 5 : 3;
         else if (N <= 64 || Ci <= 64) tile = 2;
         else tile = 1;
     }
@@ -275,6 +455,7 @@ PDT_API int pdt_conv_wgrad(const void* dy, const void* in, float* dw, long long 
         case 2: return launch_wgrad<64, 64, 2, 2>(p, s, target_blocks, budget);
         case 3: return launch_wgrad<64, 32, 2, 2>(p, s, target_blocks, budget);
         case 4: return launch_wgrad<128, 64, 2, 2>(p, s, target_blocks, budget);
+        case 5: return launch_wgrad_taps<64, 32, 2, 2, 7>(p, s, target_blocks < 2048 ? target_blocks : 768);
         default: return -6;
     }
 }
