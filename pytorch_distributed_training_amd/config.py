@@ -23,7 +23,7 @@ _REQUIRED = object()
 # is a sub-section.  ``None`` default means "optional, absent".
 _SCHEMA: Dict[str, Any] = {
     "dataset": {
-        "name": (str, _REQUIRED),              # imagenet | synthetic
+        "name": (str, _REQUIRED),              # imagenet | synthetic | synthetic_learnable (brightness encodes the label)
         "root": (str, ""),
         "n_classes": (int, _REQUIRED),
         # extensions
