@@ -238,19 +238,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(const WgradParams p)
     const int wm = wave / WN, wn = wave % WN;
 
     const int n_ct = (p.N + BMO - 1) / BMO;
-    const int nwg = p.splitk * n_ct;
+    const int groups = p.T / TAPS;            // tap groups (a 3x3 filter: one kernel row per workgroup)
+    const int nwg = p.splitk * n_ct * groups;
     int wgid;
     {
         int orig = blockIdx.x;
         int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
         wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    const int ct = wgid % n_ct;
-    const int split = wgid / n_ct;
+    const int grp = __builtin_amdgcn_readfirstlane(wgid % groups);
+    const int rest = wgid / groups;
+    const int ct = rest % n_ct;
+    const int split = rest / n_ct;
     const int co0 = ct * BMO;
     int oy[TAPS], ox[TAPS], wi_tap[TAPS];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) unpack_tap(p.taps[t], oy[t], ox[t], wi_tap[t]);
+    for (int t = 0; t < TAPS; ++t) unpack_tap(p.taps[grp * TAPS + t], oy[t], ox[t], wi_tap[t]);
 
     const long long r_begin = (long long)split * p.rows_per_split;
     long long r_end = r_begin + p.rows_per_split;
@@ -375,8 +378,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(const WgradParams p)
 
 template <int BMO, int BNC, int WM, int WN, int TAPS>
 static int launch_wgrad_taps(WgradParams& p, hipStream_t s, int target_blocks) {
-    if (p.T != TAPS || p.Ci > BNC) return -6;
-    int n_ct = (p.N + BMO - 1) / BMO;
+    if (p.T % TAPS != 0 || p.Ci > BNC) return -6;
+    int n_ct = (p.N + BMO - 1) / BMO * (p.T / TAPS);      // output tiles x tap groups
     long long max_split = (p.M + 2 * BKP - 1) / (2 * BKP);
     long long split = (target_blocks + n_ct - 1) / n_ct;
     if (split > max_split) split = max_split;
@@ -420,7 +423,8 @@ static int launch_wgrad(WgradParams& p, hipStream_t s, int target_blocks, long l
 }
 
 // tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 64x32 (one tap per workgroup), 4 = 128x64,
-//       5 = 64x32 with all 7 taps per workgroup (the stem; auto picks it for T == 7, Ci <= 32)
+//       5 = 64x32 with all 7 taps per workgroup (the stem; auto picks it for T == 7, Ci <= 32),
+//       6 / 7 = 64x64 / 128x64 with three taps (one kernel row) per workgroup, Ci <= 64
 PDT_API int pdt_conv_wgrad(const void* dy, const void* in, float* dw, long long M, int Hi, int Wi, int pix_stride,
                            int Ci, int Hg, int Wg, int IS, int N, int ldy, int wrow, int T, const signed char* offy,
                            const signed char* offx, const unsigned short* widx, int tile, int target_blocks,
@@ -447,6 +451,7 @@ PDT_API int pdt_conv_wgrad(const void* dy, const void* in, float* dw, long long 
     long long budget = (long long)(atomic_budget_mb > 0 ? atomic_budget_mb : 24) << 20;
     if (tile == 0) {
         if (Ci <= 32) tile = (T == 7) ? 5 : 3;
+        else if (T == 9 && Ci <= 64) tile = (N <= 64) ? 6 : 7;    // 3x3 on 64 channels: one kernel row per workgroup
         else if (N <= 64 || Ci <= 64) tile = 2;
         else tile = 1;
     }
@@ -456,6 +461,8 @@ PDT_API int pdt_conv_wgrad(const void* dy, const void* in, float* dw, long long 
         case 3: return launch_wgrad<64, 32, 2, 2>(p, s, target_blocks, budget);
         case 4: return launch_wgrad<128, 64, 2, 2>(p, s, target_blocks, budget);
         case 5: return launch_wgrad_taps<64, 32, 2, 2, 7>(p, s, target_blocks < 2048 ? target_blocks : 768);
+        case 6: return launch_wgrad_taps<64, 64, 2, 2, 3>(p, s, target_blocks);
+        case 7: return launch_wgrad_taps<128, 64, 2, 2, 3>(p, s, target_blocks);
         default: return -6;
     }
 }

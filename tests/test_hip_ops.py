@@ -139,6 +139,22 @@ def test_wgrad_tiles(hip, device, tile):
     assert rel_err(dw, dw_ref) < 5e-3
 
 
+@pytest.mark.parametrize("tile,Co", [(6, 64), (7, 128), (7, 192)])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_wgrad_three_taps_per_workgroup(hip, device, tile, Co, stride):
+    """3x3 weight gradient with one kernel row (three taps) per workgroup, Cin <= 64."""
+    torch.manual_seed(tile + Co)
+    H = 14
+    Ho = (H + 2 - 3) // stride + 1
+    x = rnd(5, H, H, 64, device=device)
+    dy = rnd(5, Ho, Ho, Co, device=device)
+    dw = torch.zeros(Co, 3, 3, 64, dtype=torch.float32, device=device)
+    dw_ref = torch.zeros_like(dw)
+    hip.conv_wgrad(x, dy, 3, 3, stride, 1, dw, tile=tile)
+    ref.conv_wgrad(x, dy, 3, 3, stride, 1, dw_ref)
+    assert rel_err(dw, dw_ref) < 5e-3
+
+
 @pytest.mark.parametrize("fmt", ["float_nchw", "uint8_nhwc"])
 @pytest.mark.parametrize("B,H", [(2, 64), (3, 224)])
 def test_stem(hip, device, fmt, B, H):
