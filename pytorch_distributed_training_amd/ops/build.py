@@ -64,12 +64,20 @@ def sources_digest() -> str:
     return _digest(files)
 
 
+def _stamp_text() -> str:
+    """Digest of the sources plus the identity of the library file they were built into: a library
+    left over from other sources (a checkout that restored the sources but not the binary) has a
+    different size / modification time and is rebuilt."""
+    st = os.stat(LIB)
+    return f"{sources_digest()} {st.st_size} {st.st_mtime_ns}"
+
+
 def is_up_to_date() -> bool:
     stamp = os.path.join(BUILD, "stamp")
     if not (os.path.exists(LIB) and os.path.exists(stamp)):
         return False
     with open(stamp) as f:
-        return f.read().strip() == sources_digest()
+        return f.read().strip() == _stamp_text()
 
 
 def parse_resource_remarks(text: str) -> dict:
@@ -139,7 +147,7 @@ def build(force: bool = False, verbose: bool = False, preset: str = "release") -
     with open(RESOURCES, "w") as f:
         json.dump({src: r for src, (_, r) in zip(SOURCES, results)}, f, indent=1, sort_keys=True)
     with open(os.path.join(BUILD, "stamp"), "w") as f:
-        f.write(sources_digest())
+        f.write(_stamp_text())
     return LIB
 
 
