@@ -347,16 +347,22 @@ class NativeResNet:
         layer's sums (see :meth:`_bstats`), the reduction pass over ``g`` and ``y`` is skipped.
         ``pool_idx``: ``g`` is the gradient of the max pooling behind this layer's ReLU (the stem);
         both passes gather the dense gradient from it instead of reading a materialised one."""
+        ekw = {"pool_idx": pool_idx} if pool_idx is not None else {}
+        sums = self._bn_backward_sums(u, ctx, g, mask_src, mask_mode, prereduced, pool_idx)
+        return self.ops.bn_bwd_elemt(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, sums, 1.0 / ctx.count,
+                                     mask_src, mask_mode, **ekw)
+
+    def _bn_backward_sums(self, u: ConvBNSpec, ctx: _UnitCtx, g: torch.Tensor, mask_src, mask_mode: int,
+                          prereduced: bool = False, pool_idx=None) -> torch.Tensor:
+        """First half of :meth:`_bn_backward`: the (globally reduced) sums the elementwise pass needs;
+        dgamma / dbeta are accumulated here."""
         P, ops = self.params, self.ops
         kw = {"prereduced": True} if prereduced else {}
-        ekw = {}
         if pool_idx is not None:
-            kw["pool_idx"] = ekw["pool_idx"] = pool_idx
+            kw["pool_idx"] = pool_idx
         if self.sync_bn and self._xgmi is not None and self._fused_stats:
-            sums = ops.bn_bwd_reduce(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, mask_src, mask_mode,
+            return ops.bn_bwd_reduce(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, mask_src, mask_mode,
                                      P.grad(f"{u.bn}.weight"), P.grad(f"{u.bn}.bias"), comm=self._xgmi, **kw)
-            return ops.bn_bwd_elemt(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, sums, 1.0 / ctx.count,
-                                    mask_src, mask_mode, **ekw)
         sums = ops.bn_bwd_reduce(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, mask_src, mask_mode,
                                  P.grad(f"{u.bn}.weight"), P.grad(f"{u.bn}.bias"), **kw)
         if self.sync_bn:
@@ -375,8 +381,7 @@ class NativeResNet:
                 self._host(lambda: pending.pop().wait())
             else:
                 self._host(lambda: dist.all_reduce(sums, group=group))
-        return ops.bn_bwd_elemt(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, sums, 1.0 / ctx.count,
-                                mask_src, mask_mode, **ekw)
+        return sums
 
     def _wgrad(self, fn) -> None:
         """Run a weight-gradient closure now, or (SyncBN) hold it back until the next statistics
@@ -574,7 +579,7 @@ class NativeResNet:
         return logits
 
     # ------------------------------------------------------------------ backward
-    def _conv_wgrad_fn(self, u: ConvBNSpec, x: torch.Tensor, dy: torch.Tensor):
+    def _conv_wgrad_fn(self, u: ConvBNSpec, x: torch.Tensor, dy: torch.Tensor, final: bool = True):
         P, ops, red = self.params, self.ops, self.reducer
         key = f"{u.conv}.weight"
 
@@ -592,9 +597,10 @@ class NativeResNet:
                 with torch.cuda.stream(ws):
                     ops.conv_wgrad(x, dy, u.ksize, u.ksize, u.stride, u.pad, P.grad(key))
                 self._wgrad_keep.append((x, dy))       # their memory must outlive the side-stream kernel
-                if red.completes_bucket(end):
+                if final and red.completes_bucket(end):
                     self._join_wgrad()
-            self._mark_ready(end)
+            if final:                                  # (a batch slice: the gradient is not complete yet)
+                self._mark_ready(end)
         return run
 
     def _join_wgrad(self) -> None:
@@ -616,6 +622,39 @@ class NativeResNet:
         ctx = self._ctx[u.bn]
         return {"bwd_stats": (ctx.y, ctx.mean, ctx.scale, ctx.shift, mask_mode)}
 
+    def _can_slice_bwd(self) -> bool:
+        # (the deferred weight-gradient closures of the RCCL overlap mode are whole-layer units)
+        return self._slice_bytes > 0 and not (self.sync_bn and self.syncbn_overlap and self._xgmi is None)
+
+    def _sliced_tail_backward(self, u: ConvBNSpec, prev_u: ConvBNSpec, ctx: _UnitCtx, g: torch.Tensor,
+                              prereduced: bool) -> torch.Tensor:
+        """Backward of a block's last unit in batch slices: the BatchNorm elementwise pass writes a
+        slice of dy and the data- and weight-gradient kernels of the unit's convolution consume it
+        while it is still in the memory-side cache (dy of a first-stage block is 800 MB at batch
+        512).  Sums of the consuming layers accumulate over the slices."""
+        P, ops = self.params, self.ops
+        sums = self._bn_backward_sums(u, ctx, g, None, MASK_NONE, prereduced)
+        n = self._n_slices(ctx.y)
+        B = g.shape[0]
+        step = B // n
+        key = f"{u.conv}.weight"
+        x_in = ctx.x_in
+        dy = torch.empty_like(ctx.y)
+        dx = torch.empty_like(x_in)
+        bst = self._bstats(prev_u, MASK_RECOMPUTE)
+        for c in range(n):
+            sl = slice(c * step, (c + 1) * step)
+            ops.bn_bwd_elemt(g[sl], ctx.y[sl], ctx.mean, ctx.invstd, ctx.scale, ctx.shift, sums, 1.0 / ctx.count,
+                             None, MASK_NONE, out=dy[sl])
+            self._wgrad(self._conv_wgrad_fn(u, x_in[sl], dy[sl], final=(c == n - 1)))
+            kw = {}
+            if bst is not None:
+                by, bmean, bscale, bshift, bmode = bst["bwd_stats"]
+                kw = {"bwd_stats": (by[sl], bmean, bscale, bshift, bmode)}
+            ops.conv_dgrad(dy[sl], P.compute(key), self._wt_view(key), tuple(x_in[sl].shape), u.ksize, u.ksize,
+                           u.stride, u.pad, out=dx[sl], **kw)
+        return dx
+
     def _block_backward(self, b: BlockSpec, g: torch.Tensor, g_prereduced: bool = False,
                         prev_last: Optional[ConvBNSpec] = None) -> Tuple[torch.Tensor, bool]:
         """``g``: gradient w.r.t. the block's pre-ReLU sum, i.e. ALREADY multiplied by the mask of
@@ -636,6 +675,9 @@ class NativeResNet:
         for i in range(last, -1, -1):
             u = b.units[i]
             ctx = self._ctx.pop(u.bn)
+            if i == last and i > 0 and self._can_slice_bwd() and self._n_slices(ctx.y) > 1:
+                cur = self._sliced_tail_backward(u, b.units[i - 1], ctx, cur, g_prereduced)
+                continue
             if i == last:
                 dy = self._bn_backward(u, ctx, cur, None, MASK_NONE, prereduced=g_prereduced)
             else:
