@@ -114,7 +114,10 @@ class XgmiAllReduce:
     def self_test(self, rounds: int = 48) -> bool:
         """Collective: compare against the process group's all-reduce over many sizes and
         back-to-back calls (slot reuse, flag reuse); every rank returns the same verdict."""
-        self._lib.pdt_car_set_timeout_ms(self._h, 500)
+        # Generous while testing: the first launch on a rank includes loading the code object, and
+        # the ranks reach this point at slightly different times (the control all-reduce aligns them).
+        self._lib.pdt_car_set_timeout_ms(self._h, 5000)
+        _agree(1, dist.ReduceOp.MIN, self.group, self.device)
         gen = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
         sizes = [4, 128, 512, 1024, 2048, 4096, self.max_floats]
         ok = True
