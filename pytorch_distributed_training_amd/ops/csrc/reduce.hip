@@ -525,16 +525,25 @@ PDT_API int pdt_ce_metrics(const void* logits, const void* labels, float* out, i
 }
 
 // Column sums of a small [rows][ld] bf16 matrix: out[c] += sum_r x[r][c]  (classifier bias gradient)
+// Rows are split over blockIdx.y (32 per block, independent loads) and the partial sums are added with
+// float atomics, like every other gradient: one thread walking all rows is a chain of dependent loads
+// (120 us for 512 rows).
+#define COLSUM_ROWS 32
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, float* __restrict__ out, int rows,
                                                       int N, int ld) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= N) return;
+    int r0 = blockIdx.y * COLSUM_ROWS;
+    int r1 = r0 + COLSUM_ROWS < rows ? r0 + COLSUM_ROWS : rows;
     float s = 0.0f;
-    for (int r = 0; r < rows; ++r) s += bf2f(x[(size_t)r * ld + c]);
-    out[c] += s;
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) s += bf2f(x[(size_t)r * ld + c]);
+    atomicAdd(out + c, s);
 }
 
 PDT_API int pdt_colsum_add(const void* x, float* out, int rows, int N, int ld, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, (const bf16*)x, out, rows, N, ld);
+    if (rows <= 0 || N <= 0) return 0;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256), cdiv(rows, COLSUM_ROWS)), dim3(256), 0, s, (const bf16*)x, out,
+                       rows, N, ld);
     return pdt_launch_status();
 }
