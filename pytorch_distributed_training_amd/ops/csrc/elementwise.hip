@@ -552,22 +552,54 @@ PDT_API int pdt_transpose_w(const void* w, void* wt, int Co, int T, int Ci, int 
 
 // All data-gradient weight copies in ONE launch.  Every conv weight sits at the same element
 // offset in the flat compute mirror (w_base, [Co][T][Ci]) and in the flat transposed buffer
-// (wt_base, [Ci][T][Co]); table row e = {offset, Co, T, Ci, first_block, n_blocks}; a block covers
-// TW_PER_BLOCK consecutive output elements of its entry.
+// (wt_base, [Ci][T][Co]); table row e = {offset, Co, T, Ci, first_block, n_blocks, tiled}.
+// tiled = 1 (Co and Ci multiples of 64, every ResNet body layer): a block transposes one 64 x 64
+// (co, ci) tile of one tap through LDS -- 128-byte rows in, 128-byte rows out; a plain gather reads
+// 2 bytes per cache line.  tiled = 0: a block covers TW_PER_BLOCK consecutive output elements.
 #define TW_PER_BLOCK 2048
+#define TW_COLS 7
 __global__ __launch_bounds__(256) void transpose_w_batched_kernel(const bf16* __restrict__ w_base,
                                                                    bf16* __restrict__ wt_base,
                                                                    const int* __restrict__ table, int n_entries) {
+    __shared__ bf16 tile[64][64 + 2];
     const int b = blockIdx.x;
     int lo = 0, hi = n_entries - 1;           // last entry whose first_block <= b
     while (lo < hi) {
         int mid = (lo + hi + 1) >> 1;
-        if (table[mid * 6 + 4] <= b) lo = mid; else hi = mid - 1;
+        if (table[mid * TW_COLS + 4] <= b) lo = mid; else hi = mid - 1;
     }
-    const int* e = table + lo * 6;
-    const int off = e[0], Co = e[1], T = e[2], Ci = e[3], first = e[4];
+    const int* e = table + lo * TW_COLS;
+    const int off = e[0], Co = e[1], T = e[2], Ci = e[3], first = e[4], tiled = e[6];
     const bf16* w = w_base + off;
     bf16* wt = wt_base + off;
+    if (tiled) {
+        const int nci = Ci / 64, nco = Co / 64;
+        int q = b - first;
+        const int ci0 = (q % nci) * 64; q /= nci;
+        const int co0 = (q % nco) * 64;
+        const int t = q / nco;
+        // in: rows co0..co0+63, 64 consecutive ci each (8 vectors of 16 B per row, 2 vectors per thread)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            int v = threadIdx.x + k * 256;
+            int r = v >> 3, c8 = (v & 7) * 8;
+            bf16x8 x = ld_bf16x8(w + ((size_t)(co0 + r) * T + t) * Ci + ci0 + c8);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tile[r][c8 + u] = x[u];
+        }
+        __syncthreads();
+        // out: rows ci0..ci0+63, 64 consecutive co each
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            int v = threadIdx.x + k * 256;
+            int r = v >> 3, c8 = (v & 7) * 8;
+            bf16x8 y;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) y[u] = tile[c8 + u][r];
+            st_bf16x8(wt + ((size_t)(ci0 + r) * T + t) * Co + co0 + c8, y);
+        }
+        return;
+    }
     const int total = Ci * T * Co;
     const int start = (b - first) * TW_PER_BLOCK;
 #pragma unroll

@@ -546,8 +546,9 @@ def make_transpose_table(entries, device: torch.device):
     """``entries``: (flat element offset, Co, T, Ci) per conv weight -> (int32 device table, rows, blocks)."""
     rows, first = [], 0
     for off, Co, T, Ci in entries:
-        nb = (Co * T * Ci + TW_PER_BLOCK - 1) // TW_PER_BLOCK
-        rows.append([off, Co, T, Ci, first, nb])
+        tiled = int(Co % 64 == 0 and Ci % 64 == 0 and off % 8 == 0)      # 64 x 64 tiles through LDS, 16-byte rows
+        nb = T * (Co // 64) * (Ci // 64) if tiled else (Co * T * Ci + TW_PER_BLOCK - 1) // TW_PER_BLOCK
+        rows.append([off, Co, T, Ci, first, nb, tiled])
         first += nb
     table = torch.tensor(rows, dtype=torch.int32, device=device).contiguous()
     return table, len(rows), first
