@@ -163,6 +163,7 @@ class NativeResNet:
         # the tensor, instead of re-reading the tensor for its sign in the data-gradient epilogue.
         self._relu_bits = bool(getattr(ops, "relu_bits", False)) and os.environ.get("PDT_RELU_BITS", "1") == "1"
         self._relu_bits_only = bool(getattr(ops, "bwd_stats_need_bits", False))
+        self._half_addend = bool(getattr(ops, "half_addend", False)) and os.environ.get("PDT_HALF_ADDEND", "1") == "1"
         # Step replay (see .graphs): the second step of a batch signature is recorded, later ones
         # replay the record.  "list": a command list of the backend's own launches (default);
         # "graph": HIP graphs separated by host actions.  PDT_HIP_GRAPHS: 0 = off, 1 = on,
@@ -692,14 +693,24 @@ class NativeResNet:
                 dy_first = dy
         u0 = b.units[0]
         key0 = f"{u0.conv}.weight"
+        half = False
         if b.downsample is not None:
             d = b.downsample
             ctx = self._ctx.pop(d.bn)
             dyd = self._bn_backward(d, ctx, g, None, MASK_NONE)
             keyd = f"{d.conv}.weight"
             self._wgrad(self._conv_wgrad_fn(d, x_block, dyd))
-            other = ops.conv_dgrad(dyd, P.compute(keyd), self._wt_view(keyd), tuple(x_block.shape),
-                                   d.ksize, d.ksize, d.stride, d.pad)
+            Bx, Hx, Wx, Cx = x_block.shape
+            if self._half_addend and d.ksize == 1 and d.stride == 2 and d.pad == 0 and Hx % 2 == 0 and Wx % 2 == 0:
+                # A stride-2 1x1 shortcut touches the even input pixels only: its data gradient is
+                # kept at half resolution (a plain 1x1 product) and the kernel below adds it at
+                # those pixels, instead of writing and re-reading a tensor that is 3/4 zeros.
+                other = ops.conv_dgrad(dyd, P.compute(keyd), self._wt_view(keyd), (Bx, Hx // 2, Wx // 2, Cx),
+                                       1, 1, 1, 0)
+                half = True
+            else:
+                other = ops.conv_dgrad(dyd, P.compute(keyd), self._wt_view(keyd), tuple(x_block.shape),
+                                       d.ksize, d.ksize, d.stride, d.pad)
         else:
             other = g                       # identity path
         # x_block is a post-ReLU tensor (previous block output, or the max-pooled stem activation,
@@ -709,7 +720,8 @@ class NativeResNet:
         # the fused backward sums of the previous block's last BatchNorm need the packed mask
         skw = (self._bstats(prev_last, MASK_NONE) or {}) if (bits is not None or not self._relu_bits_only) else {}
         g_in = ops.conv_dgrad(dy_first, P.compute(key0), self._wt_view(key0), tuple(x_block.shape),
-                              u0.ksize, u0.ksize, u0.stride, u0.pad, addend=other, **mkw, **skw)
+                              u0.ksize, u0.ksize, u0.stride, u0.pad, addend=other, **mkw, **skw,
+                              **({"addend_half": True} if half else {}))
         return g_in, bool(skw)
 
     def backward(self, dlogits: torch.Tensor) -> None:

@@ -65,6 +65,10 @@ struct IgemmParams {
     int N, ldo, wrow, T;
     int simple_out;
     int mask_bits;                     // mask points to packed ReLU bits (1 byte per 8 channels), not to a tensor
+    // addend is a half-resolution tensor [B][Ho/2][Wo/2][ldo] that exists at the output pixels with two
+    // even coordinates only (the data gradient of a stride-2 1x1 projection shortcut: three quarters of
+    // its full-resolution form are zeros that would be written and read back for nothing)
+    int addend_half;
     // one 32-bit word per tap: offy (int8) | offx (int8) << 8 | widx (uint16) << 16.  Sub-dword
     // entries would be fetched with VECTOR loads (no scalar byte loads on gfx9), whose waits
     // drain the tile prefetches; a dword indexed by a wave-uniform tap is one s_load_dword.
@@ -381,6 +385,17 @@ __global__ __launch_bounds__(256, ((BM * BN == 128 * 64 && !BSTAT) ? 3 : 2)) voi
                 }
             }
         }
+        // element index of the addend for GEMM row m whose output index is o; -1: no addend at that pixel
+        auto addend_index = [&](long long m, long long o) -> long long {
+            if (!p.addend_half) return o;
+            unsigned mu = (unsigned)m;
+            int b = (int)(mu / (unsigned)HgWg);
+            int rem = (int)(mu - (unsigned)b * (unsigned)HgWg);
+            int y = (int)((unsigned)rem / (unsigned)p.Wg), x = rem - y * p.Wg;
+            int yo = y * p.OS + p.oy0, xo = x * p.OS + p.ox0;
+            if ((yo | xo) & 1) return -1;
+            return (((long long)b * (p.Ho >> 1) + (yo >> 1)) * (p.Wo >> 1) + (xo >> 1)) * p.ldo + n;
+        };
         if (n < p.ldo) {                         // ldo is a multiple of 8 (checked by the launcher)
             if constexpr (!BSTAT) {
                 // plain instantiations (forward, data gradients without fused statistics of the
@@ -400,9 +415,12 @@ __global__ __launch_bounds__(256, ((BM * BN == 128 * 64 && !BSTAT) ? 3 : 2)) voi
                     bf16x8 ov = *reinterpret_cast<const bf16x8*>(Cs + row * CLD + cv * 8);
                     long long o = orow * p.ldo + n;
                     if (p.addend) {
-                        bf16x8 a = ld_bf16x8(p.addend + o);
+                        const long long ai = addend_index(m, o);
+                        if (ai >= 0) {
+                            bf16x8 a = ld_bf16x8(p.addend + ai);
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) ov[k] = f2bf(bf2f(ov[k]) + bf2f(a[k]));
+                            for (int k = 0; k < 8; ++k) ov[k] = f2bf(bf2f(ov[k]) + bf2f(a[k]));
+                        }
                     }
                     if (p.mask) {
                         if (p.mask_bits) {
@@ -456,7 +474,10 @@ __global__ __launch_bounds__(256, ((BM * BN == 128 * 64 && !BSTAT) ? 3 : 2)) voi
                         orow = ((long long)b * p.Ho + (y * p.OS + p.oy0)) * p.Wo + (x * p.OS + p.ox0);
                     }
                     oo[e] = orow * p.ldo + n;
-                    if (p.addend) av[e] = ld_stream_bf16x8(p.addend + oo[e]);      // last use of the incoming gradient
+                    if (p.addend) {                         // last use of the incoming gradient: streaming load
+                        const long long ai = addend_index(m, oo[e]);
+                        av[e] = ai >= 0 ? ld_stream_bf16x8(p.addend + ai) : zero_bf16x8();
+                    }
                     if (bwd_stats) yv[e] = ld_bf16x8(p.bstat_y + oo[e]);
                     if (p.mask) mb[e] = reinterpret_cast<const unsigned char*>(p.mask)[oo[e] >> 3];
                 }
@@ -565,8 +586,8 @@ static int launch_igemm(const IgemmParams& p, hipStream_t s) {
 }
 
 // tile: 0 = auto, 1 = 128x128x64, 2 = 128x64x64, 3 = 64x64x64, 4 = 128x64x32 (stem), 5 = 64x128x64
-static int conv_igemm_impl(const void* in, const void* wgt, void* out, const void* addend, const void* mask,
-                           int mask_bits, const float* bias, float* stat_acc, const float* stat_shift, const void* bstat_y,
+static int conv_igemm_impl(const void* in, const void* wgt, void* out, const void* addend, int addend_half,
+                           const void* mask, int mask_bits, const float* bias, float* stat_acc, const float* stat_shift, const void* bstat_y,
                            const float* bstat_mean, const float* bstat_scale, const float* bstat_shift, long long M,
                            int Hi, int Wi, int pix_stride, int Ci, int Hg, int Wg, int IS, int Ho, int Wo, int OS,
                            int oy0, int ox0, int N, int ldo, int wrow, int T, const signed char* offy,
@@ -591,6 +612,8 @@ static int conv_igemm_impl(const void* in, const void* wgt, void* out, const voi
     }
     p.Hg = Hg; p.Wg = Wg; p.IS = IS; p.Ho = Ho; p.Wo = Wo; p.OS = OS; p.oy0 = oy0; p.ox0 = ox0;
     p.N = N; p.ldo = ldo; p.wrow = wrow; p.T = T;
+    p.addend_half = (addend && addend_half) ? 1 : 0;
+    if (p.addend_half && ((Ho | Wo) & 1)) return -10;
     p.mask_bits = (mask && mask_bits) ? 1 : 0;
     if (p.mask_bits && ldo != N) return -8;        // the bit image is indexed like a dense [rows][N] tensor
     if (bstat_y && mask && !mask_bits) return -9;  // the backward-statistics variants take the mask as bits only
@@ -621,12 +644,12 @@ static int conv_igemm_impl(const void* in, const void* wgt, void* out, const voi
     }
 }
 
-PDT_API int pdt_conv_igemm(const void* in, const void* wgt, void* out, const void* addend, const void* mask,
-                           int mask_bits, const float* bias, float* stat_acc, const float* stat_shift, long long M, int Hi, int Wi,
+PDT_API int pdt_conv_igemm(const void* in, const void* wgt, void* out, const void* addend, int addend_half,
+                           const void* mask, int mask_bits, const float* bias, float* stat_acc, const float* stat_shift, long long M, int Hi, int Wi,
                            int pix_stride, int Ci, int Hg, int Wg, int IS, int Ho, int Wo, int OS, int oy0, int ox0,
                            int N, int ldo, int wrow, int T, const signed char* offy, const signed char* offx,
                            const unsigned short* widx, int tile, hipStream_t s) {
-    return conv_igemm_impl(in, wgt, out, addend, mask, mask_bits, bias, stat_acc, stat_shift, nullptr, nullptr, nullptr,
+    return conv_igemm_impl(in, wgt, out, addend, addend_half, mask, mask_bits, bias, stat_acc, stat_shift, nullptr, nullptr, nullptr,
                            nullptr, M,
                            Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, ldo, wrow, T, offy, offx, widx,
                            tile, s);
@@ -634,13 +657,13 @@ PDT_API int pdt_conv_igemm(const void* in, const void* wgt, void* out, const voi
 
 // Data gradient whose epilogue also accumulates the BatchNorm-backward sums of the consuming layer
 // (see IgemmParams::bstat_y).
-PDT_API int pdt_conv_igemm_bstats(const void* in, const void* wgt, void* out, const void* addend, const void* mask,
-                                  int mask_bits, float* stat_acc, const void* bstat_y, const float* bstat_mean,
+PDT_API int pdt_conv_igemm_bstats(const void* in, const void* wgt, void* out, const void* addend, int addend_half,
+                                  const void* mask, int mask_bits, float* stat_acc, const void* bstat_y, const float* bstat_mean,
                                   const float* bstat_scale, const float* bstat_shift, long long M, int Hi, int Wi,
                                   int pix_stride, int Ci, int Hg, int Wg, int IS, int Ho, int Wo, int OS, int oy0,
                                   int ox0, int N, int ldo, int wrow, int T, const signed char* offy,
                                   const signed char* offx, const unsigned short* widx, int tile, hipStream_t s) {
-    return conv_igemm_impl(in, wgt, out, addend, mask, mask_bits, nullptr, stat_acc, nullptr, bstat_y, bstat_mean, bstat_scale,
+    return conv_igemm_impl(in, wgt, out, addend, addend_half, mask, mask_bits, nullptr, stat_acc, nullptr, bstat_y, bstat_mean, bstat_scale,
                            bstat_shift, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, ldo, wrow, T, offy,
                            offx, widx, tile, s);
 }

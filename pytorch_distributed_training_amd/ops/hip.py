@@ -71,9 +71,9 @@ _sig("pdt_car_set_timeout_ms", _vp, _i)
 _sig("pdt_car_allreduce", _vp, _vp, _i, _vp)
 _sig("pdt_car_query", _vp, _vp)
 _sig("pdt_car_destroy", _vp)
-_sig("pdt_conv_igemm", _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+_sig("pdt_conv_igemm", _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
      _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp)
-_sig("pdt_conv_igemm_bstats", _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+_sig("pdt_conv_igemm_bstats", _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i,
      _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp)
 _sig("pdt_conv_wgrad", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp)
 
@@ -259,7 +259,7 @@ def _part(t, b0: int, b1: int):
 
 def _igemm(inp, wgt, out, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, ldo, wrow, taps: _Taps,
            addend=None, mask=None, bias=None, stat_acc=None, stat_shift=None, tile: int = 0, bstat=None,
-           mask_bits: bool = False) -> None:
+           mask_bits: bool = False, addend_half: bool = False) -> None:
     parts = _batch_parts(inp.shape[0], inp.numel() * inp.element_size())
     if parts is not None:
         B = inp.shape[0]
@@ -269,16 +269,17 @@ def _igemm(inp, wgt, out, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0
             sub = None if bstat is None else (bstat[0], bstat[1][b0:b1], *bstat[2:])
             _igemm(inp[b0:b1], wgt, out[b0:b1], (M // B) * (b1 - b0), Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS,
                    oy0, ox0, N, ldo, wrow, taps, addend=_part(addend, b0, b1), mask=_part(mask, b0, b1), bias=bias,
-                   stat_acc=stat_acc, stat_shift=stat_shift, tile=tile, bstat=sub, mask_bits=mask_bits)
+                   stat_acc=stat_acc, stat_shift=stat_shift, tile=tile, bstat=sub, mask_bits=mask_bits,
+                   addend_half=addend_half)
         return
     if bstat is not None:        # (acc, y, mean, scale-or-None, shift-or-None): BN-backward sums of the consumer
         acc, by, bmean, bscale, bshift = bstat
-        rc = _lib.pdt_conv_igemm_bstats(_p(inp), _p(wgt), _p(out), _p(addend), _p(mask), int(mask_bits), _p(acc), _p(by), _p(bmean),
+        rc = _lib.pdt_conv_igemm_bstats(_p(inp), _p(wgt), _p(out), _p(addend), int(addend_half), _p(mask), int(mask_bits), _p(acc), _p(by), _p(bmean),
                                         _p(bscale), _p(bshift), M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0,
                                         ox0, N, ldo, wrow, taps.T, taps.offy, taps.offx, taps.widx, tile, _stream())
         _check(rc, "pdt_conv_igemm_bstats")
         return
-    rc = _lib.pdt_conv_igemm(_p(inp), _p(wgt), _p(out), _p(addend), _p(mask), int(mask_bits), _p(bias), _p(stat_acc), _p(stat_shift),
+    rc = _lib.pdt_conv_igemm(_p(inp), _p(wgt), _p(out), _p(addend), int(addend_half), _p(mask), int(mask_bits), _p(bias), _p(stat_acc), _p(stat_shift),
                              M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, ldo, wrow, taps.T,
                              taps.offy, taps.offx, taps.widx, tile, _stream())
     _check(rc, "pdt_conv_igemm")
@@ -474,7 +475,8 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pa
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R: int, S: int, stride: int, pad: int,
                addend: Optional[torch.Tensor] = None, relu_mask: Optional[torch.Tensor] = None, tile: int = 0,
-               bwd_stats=None, out: Optional[torch.Tensor] = None, relu_bits: Optional[torch.Tensor] = None):
+               bwd_stats=None, out: Optional[torch.Tensor] = None, relu_bits: Optional[torch.Tensor] = None,
+               addend_half: bool = False):
     """``bwd_stats = (y, mean, scale, shift, mask_mode)`` of the BatchNorm layer that consumes the
     result ``g``: the epilogue also accumulates that layer's backward sums (what
     :func:`bn_bwd_reduce` would compute from ``g`` and ``y`` in a pass of its own); pass
@@ -487,6 +489,9 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
     dx = _out_like(out, (B, Hi, Wi, Ci), dy.device, "conv_dgrad")
     if addend is not None:
         addend = _bf16c(addend, "conv_dgrad addend")
+        want = (B, Hi // 2, Wi // 2, Ci) if addend_half else (B, Hi, Wi, Ci)
+        if tuple(addend.shape) != want or (addend_half and (Hi % 2 or Wi % 2)):
+            raise ValueError(f"conv_dgrad: addend shape {tuple(addend.shape)}, expected {want}")
     mask_src = None
     bits = relu_bits is not None
     if bits:            # packed ReLU mask of the tensor the gradient belongs to (see bn_apply bits_out)
@@ -509,7 +514,8 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
         raise ValueError("conv_dgrad: with bwd_stats the ReLU mask must be given in packed form (relu_bits)")
     if stride == 1:
         _igemm(dy, wt, dx, B * Hi * Wi, Ho, Wo, Co, Co, Hi, Wi, 1, Hi, Wi, 1, 0, 0, Ci, Ci, R * S * Co,
-               _dgrad_taps(R, S, pad, 1, 0, 0), addend=addend, mask=mask_src, tile=tile, bstat=bstat, mask_bits=bits)
+               _dgrad_taps(R, S, pad, 1, 0, 0), addend=addend, mask=mask_src, tile=tile, bstat=bstat, mask_bits=bits,
+               addend_half=addend_half)
         return dx
     for ph in range(stride):
         for pw in range(stride):
@@ -519,7 +525,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
                 continue
             _igemm(dy, wt, dx, B * Hg * Wg, Ho, Wo, Co, Co, Hg, Wg, 1, Hi, Wi, stride, ph, pw, Ci, Ci, R * S * Co,
                    _dgrad_taps(R, S, pad, stride, ph, pw), addend=addend, mask=mask_src, tile=tile, bstat=bstat,
-                   mask_bits=bits)
+                   mask_bits=bits, addend_half=addend_half)
     return dx
 
 
@@ -594,6 +600,7 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps: float):
 
 relu_bits = True             # bn_apply/bn_apply2(bits_out=...) and conv_dgrad(relu_bits=...)
 bwd_stats_need_bits = True   # conv_dgrad(bwd_stats=...) takes its ReLU mask in packed form only
+half_addend = True           # conv_dgrad(addend_half=True): addend given at the even output pixels only
 
 
 def new_relu_bits(like: torch.Tensor) -> torch.Tensor:

@@ -102,7 +102,7 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pa
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: Optional[torch.Tensor], in_shape, R: int, S: int,
                stride: int, pad: int, addend: Optional[torch.Tensor] = None,
                relu_mask: Optional[torch.Tensor] = None, relu_bits: Optional[torch.Tensor] = None,
-               **_) -> torch.Tensor:
+               addend_half: bool = False, **_) -> torch.Tensor:
     """``dx = (conv_transpose(dy, w) [+ addend]) [* (relu_mask > 0)]`` ; ``in_shape = (B, Hi, Wi, Ci)``.
     ``relu_bits``: the same mask in packed form (see :func:`bn_apply`).
 
@@ -115,6 +115,10 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: Optional[torch.Tensor], in
     dx = _nhwc(dx)
     dx = dx.to(dy.dtype)
     if addend is not None:
+        if addend_half:          # given at the output pixels with two even coordinates only, zero elsewhere
+            full = torch.zeros_like(dx)
+            full[:, ::2, ::2] = addend
+            addend = full
         dx = (dx.float() + addend.float()).to(dy.dtype)
     if relu_bits is not None:
         dx = dx * _unpack_bits(relu_bits)
@@ -172,6 +176,7 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps: float):
 
 
 relu_bits = True             # bn_apply/bn_apply2(bits_out=...) and conv_dgrad(relu_bits=...)
+half_addend = True           # conv_dgrad(addend_half=True)
 _BIT_WEIGHTS = (1, 2, 4, 8, 16, 32, 64, 128)
 
 

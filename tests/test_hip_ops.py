@@ -368,6 +368,42 @@ def test_packed_relu_mask_roundtrip(hip, device, C, H, stride, k):
                        bwd_stats=(y, mean, None, None, ref.MASK_NONE))
 
 
+@pytest.mark.parametrize("k,stride,pad", [(1, 1, 0), (3, 2, 1), (3, 1, 1)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_half_resolution_addend(hip, device, k, stride, pad, fused):
+    """conv_dgrad(addend_half=True): an addend stored at the even output pixels only equals the full
+    tensor with zeros at the other pixels."""
+    torch.manual_seed(k + stride)
+    B, H, Ci, Co = 3, 12, 128, 64
+    Ho = (H + 2 * pad - k) // stride + 1
+    dy = rnd(B, Ho, Ho, Co, device=device)
+    w = rnd(Co, k, k, Ci, device=device, scale=0.05)
+    wt = torch.empty(Ci, k, k, Co, dtype=torch.bfloat16, device=device)
+    hip.transpose_weights(w, wt)
+    half = rnd(B, H // 2, H // 2, Ci, device=device)
+    full = torch.zeros(B, H, H, Ci, dtype=torch.bfloat16, device=device)
+    full[:, ::2, ::2] = half
+    y = rnd(B, H, H, Ci, device=device)
+    bits = hip.new_relu_bits(y)
+    ref._pack_bits(y, bits)
+    mean = torch.randn(Ci, device=device) * 0.1
+    kw = {"bwd_stats": (y, mean, None, None, ref.MASK_NONE)} if fused else {}
+
+    def sums():
+        return hip.bn_bwd_reduce(y, y, mean, torch.ones(Ci, device=device), None, None, None, ref.MASK_NONE,
+                                 prereduced=True) if fused else None
+
+    a = hip.conv_dgrad(dy, w, wt, (B, H, H, Ci), k, k, stride, pad, addend=full, relu_bits=bits, **kw)
+    sa = sums()
+    b = hip.conv_dgrad(dy, w, wt, (B, H, H, Ci), k, k, stride, pad, addend=half, addend_half=True, relu_bits=bits, **kw)
+    sb = sums()
+    assert torch.equal(a, b)
+    if fused:
+        assert torch.allclose(sa, sb, rtol=1e-4, atol=1e-3)
+    c = ref.conv_dgrad(dy, w, None, (B, H, H, Ci), k, k, stride, pad, addend=half, addend_half=True, relu_bits=bits)
+    assert rel_err(b, c) < 1.5e-2
+
+
 @pytest.mark.parametrize("B,H,C", [(2, 112, 64), (3, 30, 64), (1, 9, 128)])
 def test_bn_backward_through_fused_relu_maxpool(hip, device, B, H, C):
     """BatchNorm-backward passes fed with the POOLED gradient + winner indices against the
