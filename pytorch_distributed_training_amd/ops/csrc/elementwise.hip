@@ -245,10 +245,11 @@ __global__ __launch_bounds__(256) void input_pad_kernel(const void* __restrict__
     long long total = (long long)B * Hp * Wp;
     long long stride = (long long)gridDim.x * blockDim.x;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        int wp = (int)(idx % Wp);
-        long long t = idx / Wp;
-        int hp = (int)(t % Hp);
-        int b = (int)(t / Hp);
+        const unsigned iu = (unsigned)idx;                    // total < 2^31 (checked by the launcher)
+        const unsigned t = iu / (unsigned)Wp;
+        int wp = (int)(iu - t * (unsigned)Wp);
+        int b = (int)(t / (unsigned)Hp);
+        int hp = (int)(t - (unsigned)b * (unsigned)Hp);
         int h = hp - 3, w = wp - 3;
         bf16x4 o;
         o[0] = o[1] = o[2] = o[3] = f2bf(0.0f);
@@ -273,6 +274,7 @@ __global__ __launch_bounds__(256) void input_pad_kernel(const void* __restrict__
 PDT_API int pdt_input_pad(const void* src, void* dst, int B, int H, int W, int Hp, int Wp, int is_u8, float m0,
                           float m1, float m2, float s0, float s1, float s2, hipStream_t s) {
     long long total = (long long)B * Hp * Wp;
+    if (total >= 0x7fffffffLL) return -3;
     dim3 grid(ew_grid(total, 2)), block(256);
     if (is_u8) hipLaunchKernelGGL((input_pad_kernel<true>), grid, block, 0, s, src, (bf16*)dst, B, H, W, Hp, Wp, m0, m1, m2, 1.0f / s0, 1.0f / s1, 1.0f / s2);
     else hipLaunchKernelGGL((input_pad_kernel<false>), grid, block, 0, s, src, (bf16*)dst, B, H, W, Hp, Wp, m0, m1, m2, 1.0f, 1.0f, 1.0f);
@@ -297,11 +299,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16* __restrict
     long long total = (long long)B * Ho * Wo * cvec;
     long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        int cv = (int)(i % cvec);
-        long long t = i / cvec;
-        int wo = (int)(t % Wo); t /= Wo;
-        int ho = (int)(t % Ho);
-        int b = (int)(t / Ho);
+        // 32-bit index arithmetic (total < 2^31, checked by the launchers)
+        const unsigned iu = (unsigned)i;
+        unsigned t = iu / (unsigned)cvec;
+        int cv = (int)(iu - t * (unsigned)cvec);
+        unsigned t2 = t / (unsigned)Wo;
+        int wo = (int)(t - t2 * (unsigned)Wo);
+        int b = (int)(t2 / (unsigned)Ho);
+        int ho = (int)(t2 - (unsigned)b * (unsigned)Ho);
         float best[8], sc[8], sh[8];
         unsigned char bi[8];
 #pragma unroll
@@ -401,11 +406,12 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_elemt_kernel(
     }
     for (; t < nvec; t += stride) {
         const long long i = nvec - 1 - t;               // back to front, like bn_bwd_elemt
-        long long r = i / cvec;
-        int w = (int)(r % W);
-        r /= W;
-        int h = (int)(r % H);
-        int b = (int)(r / H);
+        // 32-bit index arithmetic (nvec < 2^31, checked by the launcher)
+        const unsigned ru = (unsigned)i / (unsigned)cvec;
+        const unsigned tu = ru / (unsigned)W;
+        int w = (int)(ru - tu * (unsigned)W);
+        int b = (int)(tu / (unsigned)H);
+        int h = (int)(tu - (unsigned)b * (unsigned)H);
         bf16x8 yv = ld_stream_bf16x8(y + i * 8);
         float g[8];
         pool3x3s2_grad8(dout, idx, b, h, w, cv, cvec, Ho, Wo, g);
@@ -427,6 +433,7 @@ PDT_API int pdt_pool_bn_bwd_elemt(const void* dout, const void* idx, const void*
     if (Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1 || B < 1) return -2;
     int cvec = C / 8;
     long long nvec = (long long)B * H * W * cvec;
+    if (nvec >= 0x7fffffffLL) return -3;
     hipLaunchKernelGGL(pool_bn_bwd_elemt_kernel, dim3(ew_grid(nvec, 4)), dim3(256), 0, s, (const bf16*)dout,
                        (const unsigned char*)idx, (const bf16*)y, mean, invstd, scale, shift, sums, inv_count,
                        (bf16*)dx, nvec, cvec, C, H, W, Ho, Wo);
@@ -437,6 +444,7 @@ PDT_API int pdt_maxpool_fwd(const void* x, void* out, void* idx, int B, int H, i
                             hipStream_t s) {
     if (C % 8) return -1;
     long long total = (long long)B * Ho * Wo * (C / 8);
+    if (total >= 0x7fffffffLL) return -3;
     hipLaunchKernelGGL(maxpool_fwd_kernel<false>, dim3(ew_grid(total, 1)), dim3(256), 0, s, (const bf16*)x, (bf16*)out,
                        (unsigned char*)idx, B, H, W, C, Ho, Wo, nullptr, nullptr);
     return pdt_launch_status();
@@ -446,6 +454,7 @@ PDT_API int pdt_bn_relu_maxpool_fwd(const void* y, const float* scale, const flo
                                     int H, int W, int C, int Ho, int Wo, hipStream_t s) {
     if (C % 8) return -1;
     long long total = (long long)B * Ho * Wo * (C / 8);
+    if (total >= 0x7fffffffLL) return -3;
     hipLaunchKernelGGL(maxpool_fwd_kernel<true>, dim3(ew_grid(total, 1)), dim3(256), 0, s, (const bf16*)y, (bf16*)out,
                        (unsigned char*)idx, B, H, W, C, Ho, Wo, scale, shift);
     return pdt_launch_status();

@@ -331,10 +331,12 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(
     long long r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
     for (long long r = r0 + row_lane; r < r1; r += rl) {
-        int w = (int)(r % W);
-        long long t = r / W;
-        int h = (int)(t % H);
-        int b = (int)(t / H);
+        // 32-bit index arithmetic (the launcher checks rows < 2^31): 64-bit divisions cost more than the loads
+        const unsigned ru = (unsigned)r;
+        const unsigned tu = ru / (unsigned)W;
+        int w = (int)(ru - tu * (unsigned)W);
+        int b = (int)(tu / (unsigned)H);
+        int h = (int)(tu - (unsigned)b * (unsigned)H);
         bf16x8 yv = ld_bf16x8(y + r * C + c0);
         float g[8];
         pool3x3s2_grad8(dout, idx, b, h, w, c0 / 8, cvec, Ho, Wo, g);
@@ -355,6 +357,7 @@ PDT_API int pdt_pool_bn_bwd_reduce_accum(const void* dout, const void* idx, cons
     if (C % 8 != 0 || (C / 8 < 32 ? 256 % (C / 8) != 0 : (C / 8) % 32 != 0)) return -1;
     if (Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1 || B < 1) return -2;
     long long rows = (long long)B * H * W;
+    if (rows >= 0x7fffffffLL) return -3;
     ColGeom gm = col_geom(rows, C);
     hipLaunchKernelGGL(pool_bn_bwd_reduce_kernel, dim3(gm.slabs * gm.row_chunks), dim3(256), 0, s, (const bf16*)dout,
                        (const unsigned char*)idx, (const bf16*)y, mean, scale, shift, acc, rows, C, H, W, Ho, Wo, gm.cv,
