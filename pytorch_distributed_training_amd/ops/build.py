@@ -60,7 +60,8 @@ def _digest(paths: List[str]) -> str:
 
 
 def sources_digest() -> str:
-    files = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h")]
+    """Every file under ``csrc/`` counts (kernels and all the headers they include)."""
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     return _digest(files)
 
 
