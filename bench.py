@@ -2,10 +2,14 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-For N > 1 launch one rank per GPU, e.g.
+For N > 1 there is one rank per GPU.  Either a launcher starts them, e.g.
 ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
---master-port P bench.py --gpus N --steps K --warmup W``; RANK / LOCAL_RANK / WORLD_SIZE /
-MASTER_* are read from the environment and collectives go over RCCL.
+--master-port P bench.py --gpus N --steps K --warmup W`` (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* are read from the environment), or -- from a plain shell, with none of those set --
+this script starts the N ranks itself: the parent makes no GPU call, runs N fresh
+interpreters of this file with the rendezvous variables set (the way upstream's trainer
+spawns its workers, reference ``train_distributed.py:125-135``, ``train.sh:6-14``), relays
+rank 0's JSON line and exits non-zero if any rank failed.  Collectives go over RCCL.
 
 A step is the full training iteration of the trainer: host-to-device copy of a synthetic
 uint8 ImageNet-shaped batch (prefetched on a copy stream), fused normalise/layout kernel,
@@ -19,6 +23,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -62,6 +68,56 @@ def synthetic_batches(batch: int, image_size: int, n_classes: int, fmt: str, dev
         i += 1
 
 
+def _free_port() -> int:
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def self_launch(n_ranks: int, argv, timeout_s: float = 3000.0, script: str = None) -> int:
+    """Start ``n_ranks`` fresh interpreters of this script, one per GPU (ranks share GPUs round
+    robin when fewer are visible).  Called before this process has touched the GPU; it never
+    does.  Rank 0's stdout is this process's stdout, the other ranks write to stderr."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL and the xGMI exchange need it
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("MASTER_PORT", str(_free_port()))
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n_ranks)
+    procs = []
+    for rank in range(n_ranks):
+        renv = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__), *argv], env=renv,
+                                      stdout=None if rank == 0 else sys.stderr))
+    deadline = time.monotonic() + timeout_s
+    codes = [None] * n_ranks
+    try:
+        while any(c is None for c in codes):
+            for i, pr in enumerate(procs):
+                if codes[i] is None:
+                    codes[i] = pr.poll()
+            failed = [c for c in codes if c not in (None, 0)]
+            if failed or time.monotonic() > deadline:
+                break
+            time.sleep(0.05)
+    finally:
+        # fail fast: one dead rank leaves the others blocked in a collective
+        for i, pr in enumerate(procs):
+            if codes[i] is None:
+                pr.terminate()
+        for i, pr in enumerate(procs):
+            if codes[i] is None:
+                try:
+                    codes[i] = pr.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+                    codes[i] = pr.wait()
+    bad = [(i, c) for i, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,15 +136,16 @@ def main() -> int:
     ap.add_argument("--backend", type=str, default="nccl")
     args = ap.parse_args()
 
+    if args.gpus > 1 and not dist_env.env_launch_detected():
+        return self_launch(args.gpus, sys.argv[1:])          # nothing here has touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 or args.gpus > 1 or dist_env.env_launch_detected():
         if world != args.gpus:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU with "
-                  "torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
             return 2
-        info = dist_env.init_from_env(args.backend)
+        info = dist_env.init_from_env(args.backend, device_type="cuda")
     else:
-        info = dist_env.init_distributed(args.backend, None, 1, 0, 0, 1)
+        info = dist_env.init_distributed(args.backend, None, 1, 0, 0, 1, device_type="cuda")
     device = info.device
     if device.type != "cuda":
         print("bench.py: no GPU visible", file=sys.stderr)
@@ -119,9 +176,12 @@ def main() -> int:
     loss = None
     for _ in range(args.warmup):
         loss = step()
-    if args.engine == "native" and not engine.model.check_comm_health():
-        for _ in range(args.warmup):              # the exchange path changed: warm the new one up
-            loss = step()
+    if not engine.check_health():                 # collective; a failed exchange would have poisoned the warm-up
+        print("bench.py: communication failure during warm-up", file=sys.stderr)
+        return 3
+    native = args.engine == "native"
+    if native:
+        engine.model.reducer.start_timing()
     if info.distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -138,6 +198,8 @@ def main() -> int:
     if info.distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    exposed = engine.model.reducer.exposed_ms() if native else None
+    healthy = engine.check_health()
     final_loss = float(loss) if loss is not None else float("nan")
     global_batch = args.batch * info.world_size
     value = global_batch * args.steps / elapsed
@@ -161,20 +223,29 @@ def main() -> int:
                 "parallelism": f"dp{info.world_size}" + ("+syncbn" if (args.sync_bn and info.world_size > 1) else ""),
                 "engine": args.engine, "optimizer": "SGD momentum 0.9 wd 1e-4", "final_loss": round(final_loss, 4),
                 "peak_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
+                "rccl_world": dist.get_world_size() if dist.is_initialized() else 1,
+                "backend": dist.get_backend() if dist.is_initialized() else None,
+                "grad_buckets": len(engine.model.buckets) if native else None,
                 "grad_buckets_reduced_per_step": (
-                    engine.model.reducer.stats["launched"] // max(args.steps + args.warmup, 1)
-                    if args.engine == "native" else None),
+                    engine.model.reducer.stats["launched"] // max(engine.model.reducer.stats["steps"], 1)
+                    if native else None),
+                "grad_allreduce_mb_per_step": (
+                    round(engine.model.reducer.stats["bytes"] / max(engine.model.reducer.stats["steps"], 1) / 2 ** 20, 2)
+                    if native else None),
+                # time per step the compute stream stood still at the end of backward waiting for the
+                # communication stream (last all-reduce + the per-bucket optimizer updates not yet done)
+                "exposed_comm_ms_per_step": round(exposed, 4) if exposed is not None else None,
+                "optimizer_in_backward": engine.model.optimizer_in_backward if native else None,
+                "comm_healthy": bool(healthy),
                 "host_submit_ms_per_step": round(1e3 * enqueue / args.steps, 3),
                 "syncbn_comm": engine.model.syncbn_comm if (args.engine == "native" and engine.model.sync_bn) else None,
-                "step_replay": ((engine.model.step_replay if engine.model.hip_graphs and
-                                 any(p is not None for p in engine.model._plans.values()) else "off")
-                                if args.engine == "native" else None),
+                "step_replay": engine.model.active_replay_mode() if native else None,
                 "sync_bn_active": bool(engine.model.sync_bn) if args.engine == "native" else None,
             },
         }), flush=True)
     if dist.is_initialized():
         dist_env.shutdown()
-    return 0
+    return 0 if healthy else 3
 
 
 if __name__ == "__main__":

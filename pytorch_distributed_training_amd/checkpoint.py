@@ -23,7 +23,7 @@ from __future__ import annotations
 
 import os
 import random
-from typing import Any, Dict, Optional
+from typing import Any, Dict, List, Optional
 
 import numpy as np
 import torch
@@ -122,3 +122,28 @@ def latest_checkpoint(directory: str) -> Optional[str]:
             if it > best_it:
                 best, best_it = os.path.join(directory, fn), it
     return best
+
+
+def prune_checkpoints(directory: str, keep: int) -> List[str]:
+    """Delete all but the ``keep`` newest periodic checkpoints (``iter_<n>.pth``) of ``directory``
+    and return the removed paths.  Files with other names (explicitly tagged saves) stay.  A
+    450 000-iteration run with a checkpoint every 2000 iterations would otherwise leave 225
+    full training states (~300 MB each for ResNet-50) behind."""
+    if keep <= 0 or not directory or not os.path.isdir(directory):
+        return []
+    found = []
+    for fn in os.listdir(directory):
+        if fn.startswith("iter_") and fn.endswith(".pth"):
+            try:
+                found.append((int(fn[5:-4]), os.path.join(directory, fn)))
+            except ValueError:
+                continue
+    found.sort()
+    removed = []
+    for _, path in found[:-keep]:
+        try:
+            os.remove(path)
+            removed.append(path)
+        except OSError:
+            pass
+    return removed

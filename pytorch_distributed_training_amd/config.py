@@ -72,6 +72,9 @@ _SCHEMA: Dict[str, Any] = {
         "syncbn_overlap": (bool, False),       # async BN-backward all-reduce overlapped with the previous wgrad
         "engine": (str, "native"),             # native | torch
         "max_val_batches": (int, None),
+        "keep_last_checkpoints": (int, 3),     # periodic checkpoints kept on disk (0 = keep all); named tags are never pruned
+        "grad_allreduce_dtype": (str, "fp32"), # fp32 | bf16: wire format of the gradient buckets
+        "optimizer_in_backward": (bool, True), # per-bucket fused update behind each bucket's all-reduce
     },
     "validation": {
         "batch_size": (int, None),
@@ -84,6 +87,7 @@ _SCHEMA: Dict[str, Any] = {
         "profile": (bool, False),              # roctx ranges around step phases
         "debug_sync_check": (int, 0),          # every N iters compare param hashes across ranks
         "collective_timeout_s": (int, 1800),
+        "xgmi_timeout_s": ((int, float), None),# bound of a wait inside the xGMI SyncBN exchange; default: collective_timeout_s
         "deterministic": (bool, False),
         "hip_graphs": (bool, True),            # native engine on GPU: record the step once, then replay it
         "step_replay": (str, "list"),          # list (command list of stream launches) | graph (HIP graphs) | off

@@ -55,11 +55,19 @@ def _random_resized_crop_box(w: int, h: int, rng: random.Random, scale=(0.08, 1.
 
 
 class TrainTransform:
-    """RandomResizedCrop(size) + random horizontal flip -> uint8 HWC array."""
+    """RandomResizedCrop(size) + random horizontal flip -> uint8 HWC array.
 
-    def __init__(self, size: int = 224) -> None:
+    The generator is private to the transform and must be given its own seed in every process
+    that draws from it (:meth:`reseed`; the loader does that per (seed, rank, worker) --
+    forked loader workers would otherwise all continue the parent's stream and cut identical
+    crops)."""
+
+    def __init__(self, size: int = 224, seed: int = 0) -> None:
         self.size = size
-        self.rng = random.Random()
+        self.rng = random.Random(seed)
+
+    def reseed(self, seed: int) -> None:
+        self.rng = random.Random(seed)
 
     def __call__(self, img):
         from PIL import Image

@@ -40,6 +40,26 @@ def make_iter_dataloader(loader: DataLoader, start_epoch: int = 0, skip_batches:
         epoch += 1
 
 
+def augmentation_seed(seed: int, rank: int, worker_id: int) -> int:
+    """Distinct, reproducible stream per (run seed, rank, loader worker); ``worker_id`` -1 is the
+    in-process loader (``num_workers == 0``)."""
+    return (int(seed) * 1000003 + int(rank) * 7919 + int(worker_id) + 1) & 0x7FFFFFFFFFFFFFFF
+
+
+class _SeedWorker:
+    """``worker_init_fn`` (a picklable object: loader workers may be spawned): gives the dataset's
+    random transform of this worker its own stream."""
+
+    def __init__(self, seed: int, rank: int) -> None:
+        self.seed, self.rank = seed, rank
+
+    def __call__(self, worker_id: int) -> None:
+        info = torch.utils.data.get_worker_info()
+        transform = getattr(info.dataset, "transform", None) if info is not None else None
+        if hasattr(transform, "reseed"):
+            transform.reseed(augmentation_seed(self.seed, self.rank, worker_id))
+
+
 def build_loader(dataset: Dataset, batch_size: int, num_workers: int, train: bool, world_size: int, rank: int,
                  seed: int = 0, pin_memory: bool = True, pad_val: bool = False) -> DataLoader:
     """Per-rank loader: shuffled + ``drop_last`` shards for training, ordered shards for validation."""
@@ -47,10 +67,13 @@ def build_loader(dataset: Dataset, batch_size: int, num_workers: int, train: boo
         len(dataset), num_replicas=world_size, rank=rank, shuffle=train, seed=seed,
         drop_last=train, pad=pad_val if not train else False,
     )
+    transform = getattr(dataset, "transform", None)
+    if hasattr(transform, "reseed"):
+        transform.reseed(augmentation_seed(seed, rank, -1))
     return DataLoader(
         dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers,
         pin_memory=pin_memory and torch.cuda.is_available(), drop_last=train,
-        persistent_workers=num_workers > 0,
+        persistent_workers=num_workers > 0, worker_init_fn=_SeedWorker(seed, rank),
     )
 
 

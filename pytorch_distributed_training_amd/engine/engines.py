@@ -37,8 +37,10 @@ def _optimizer_kwargs(cfg: Dict[str, Any]) -> Dict[str, Any]:
 class NativeEngine:
     name = "native"
 
-    def __init__(self, cfg: Dict[str, Any], device: torch.device, ops_backend: str = "auto", group=None) -> None:
+    def __init__(self, cfg: Dict[str, Any], device: torch.device, ops_backend: str = "auto", group=None,
+                 logger=None) -> None:
         tr = cfg["training"]
+        rt = cfg.get("runtime", {})
         self.device = torch.device(device)
         self.ops = get_ops(self.device, ops_backend)
         precision = tr.get("precision", "bf16")
@@ -51,7 +53,10 @@ class NativeEngine:
             hip_graphs=cfg.get("runtime", {}).get("hip_graphs", True),
             syncbn_overlap=tr.get("syncbn_overlap", False),
             syncbn_comm=tr.get("syncbn_comm", "auto"),
-            step_replay=cfg.get("runtime", {}).get("step_replay", "list"),
+            step_replay=rt.get("step_replay", "list"),
+            grad_allreduce_dtype=tr.get("grad_allreduce_dtype", "fp32"),
+            xgmi_timeout_s=float(rt.get("xgmi_timeout_s") or rt.get("collective_timeout_s", 1800)),
+            logger=logger,
         )
         # Same-seed initialisation on every rank (upstream seeds every worker identically,
         # train_distributed.py:141-142); the eager module is only the initialiser here.
@@ -63,13 +68,25 @@ class NativeEngine:
         self.optimizer: FlatSGD = opt_cls(self.model.params, self.ops, no_wd_bn=tr.get("no_wd_bn", False),
                                           **_optimizer_kwargs(cfg))
         self.world = self.model.world
+        if tr.get("optimizer_in_backward", True):
+            self.model.attach_optimizer(self.optimizer)
 
     def train_step(self, img: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
         loss = self.model.forward_backward(img, label)
+        # a timed-out statistics exchange has poisoned this replica with NaN: end the job now
+        # (a host-memory read, no synchronisation)
+        self.model.raise_on_comm_failure()
         with trace_range("optimizer"):
-            self.optimizer.step(grad_scale=self.model.reducer.grad_scale)
+            if self.model.optimizer_in_backward:
+                self.optimizer.finish_step()      # the update itself ran bucket by bucket inside backward
+            else:
+                self.optimizer.step(grad_scale=self.model.reducer.grad_scale)
             self.model.refresh_derived_weights()
         return loss
+
+    def check_health(self) -> bool:
+        """Collective + synchronising: no rank has seen a communication failure."""
+        return self.model.check_comm_health()
 
     def eval_step(self, img: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
         return self.model.eval_step(img, label)
@@ -96,13 +113,14 @@ class NativeEngine:
     def describe(self) -> str:
         m = self.model
         return (f"NativeEngine(ops={self.ops.name}, dtype={m.dtype}, params={m.params.num_parameters()}, "
-                f"buckets={len(m.buckets)}, sync_bn={m.sync_bn}, world={m.world})")
+                f"buckets={len(m.buckets)}, sync_bn={m.sync_bn}, syncbn_comm={m.syncbn_comm if m.sync_bn else None}, "
+                f"world={m.world}, step_replay={m.step_replay}, optimizer_in_backward={m.optimizer_in_backward})")
 
 
 class TorchEngine:
     name = "torch"
 
-    def __init__(self, cfg: Dict[str, Any], device: torch.device, group=None, **_) -> None:
+    def __init__(self, cfg: Dict[str, Any], device: torch.device, group=None, **_) -> None:  # noqa: D401
         tr = cfg["training"]
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
@@ -160,6 +178,9 @@ class TorchEngine:
     def prepare_validation(self) -> None:
         pass
 
+    def check_health(self) -> bool:
+        return True
+
     def model_state_dict(self) -> Dict[str, torch.Tensor]:
         return {k: v.detach().clone() for k, v in self.module.state_dict().items()}
 
@@ -179,10 +200,10 @@ class TorchEngine:
         return f"TorchEngine(bf16={self.bf16}, world={self.world})"
 
 
-def build_engine(cfg: Dict[str, Any], device: torch.device, group=None, ops_backend: str = "auto"):
+def build_engine(cfg: Dict[str, Any], device: torch.device, group=None, ops_backend: str = "auto", logger=None):
     kind = cfg["training"].get("engine", "native")
     if kind == "native":
-        return NativeEngine(cfg, device, ops_backend=ops_backend, group=group)
+        return NativeEngine(cfg, device, ops_backend=ops_backend, group=group, logger=logger)
     if kind == "torch":
         return TorchEngine(cfg, device, group=group)
     raise ValueError(f"unknown engine '{kind}'")

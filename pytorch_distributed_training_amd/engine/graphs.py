@@ -92,7 +92,7 @@ class ListProgram:
     def __init__(self, device: torch.device, hip_ops) -> None:
         self.device = device
         self._ops = hip_ops
-        self.items: List[Tuple[Callable, tuple]] = []
+        self.items: List[Tuple[Optional[Callable], object]] = []    # (library fn, args) or (None, host action)
         self.pool = torch.cuda.MemPool()
         self.stream = torch.cuda.current_stream(device).cuda_stream
         self.num_host_actions = 0
@@ -101,8 +101,15 @@ class ListProgram:
         self._ops.begin_recording(self.items)
 
     def host(self, fn: Callable[[], None]) -> None:
-        fn()
-        self.items.append((fn, ()))
+        """A host action (collective, event/stream call, per-bucket optimizer update): run now with
+        recording suspended -- library calls it makes belong to the action, which replays them
+        itself -- and listed as one item whose return value means nothing."""
+        self._ops.end_recording()
+        try:
+            fn()
+        finally:
+            self._ops.begin_recording(self.items)
+        self.items.append((None, fn))
         self.num_host_actions += 1
 
     def finish(self) -> None:
@@ -114,7 +121,9 @@ class ListProgram:
         if torch.cuda.current_stream(self.device).cuda_stream != self.stream:
             raise RuntimeError("a recorded step must be replayed on the stream it was recorded on")
         for fn, args in self.items:
-            if fn(*args):
+            if fn is None:
+                args()                     # host action: whatever it returns (e.g. Work.wait() -> True) is not a status
+            elif fn(*args):                # library call: non-zero is a hipError_t / argument error
                 raise RuntimeError(f"replayed call {getattr(fn, '__name__', fn)} failed")
 
     @property

@@ -32,6 +32,8 @@ program is exercised by the CPU/gloo tests and checked against the eager model
 """
 from __future__ import annotations
 
+import hashlib
+import logging
 import os
 from typing import Dict, List, Optional, Tuple
 
@@ -45,6 +47,17 @@ from ..utils.profiling import trace_range
 from .params import FlatParams, make_buckets
 
 MASK_NONE, MASK_TENSOR, MASK_RECOMPUTE = _ref.MASK_NONE, _ref.MASK_TENSOR, _ref.MASK_RECOMPUTE
+
+_log = logging.getLogger(__name__)
+
+
+class ReplicaMismatchError(RuntimeError):
+    """The ranks of a job were not built alike (model, class count, bucket layout)."""
+
+
+class CommFailure(RuntimeError):
+    """The in-kernel xGMI statistics exchange timed out: the step's results are poisoned (NaN)."""
+
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
@@ -81,12 +94,14 @@ class NativeResNet:
                  sync_bn: bool = False, group=None, bucket_cap_mb: float = 25.0, first_bucket_mb: float = 1.0,
                  overlap_comm: bool = True, bn_momentum: float = 0.1, bn_eps: float = 1e-5,
                  hip_graphs: bool = False, syncbn_overlap: bool = False, syncbn_comm: str = "auto",
-                 step_replay: str = "list") -> None:
+                 step_replay: str = "list", grad_allreduce_dtype: str = "fp32", xgmi_timeout_s: float = 1800.0,
+                 logger: Optional[logging.Logger] = None) -> None:
         self.spec = spec
         self.device = torch.device(device)
         self.ops = ops
         self.dtype = compute_dtype
         self.group = group
+        self.log = logger or _log
         initialized = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if initialized else 1
         forced = initialized and os.environ.get("PDT_FORCE_COLLECTIVES") == "1"   # debug: see GradReducer
@@ -101,7 +116,11 @@ class NativeResNet:
         assert sorted(order) == sorted(spec.parameter_keys())
         self.params = FlatParams([(k, schema[k][0]) for k in order], self.device, compute_dtype)
         self.buckets = make_buckets(self.params, bucket_cap_mb, first_bucket_mb)
-        self.reducer = GradReducer(self.params.g, self.buckets, group=group, overlap=overlap_comm)
+        if grad_allreduce_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"grad_allreduce_dtype must be fp32 or bf16, not {grad_allreduce_dtype!r}")
+        self.reducer = GradReducer(self.params.g, self.buckets, group=group, overlap=overlap_comm,
+                                   comm_dtype=torch.bfloat16 if grad_allreduce_dtype == "bf16" else None)
+        self._optimizer = None           # set by attach_optimizer: its update then runs per gradient bucket
 
         # BatchNorm running statistics: flat fp32 buffers, one slot per BN in forward order.
         self.units = spec.conv_bn_units()
@@ -140,7 +159,7 @@ class NativeResNet:
                 and os.environ.get("PDT_SYNCBN_COMM", syncbn_comm) in ("auto", "xgmi"):
             from ..parallel.xgmi_allreduce import XgmiAllReduce
             x = XgmiAllReduce.create(group, self.device)
-            if x is not None and not x.self_test():
+            if x is not None and not x.self_test(production_timeout_s=xgmi_timeout_s):
                 x.close()
                 x = None
             self._xgmi = x
@@ -184,6 +203,7 @@ class NativeResNet:
             self._wgrad_stream = torch.cuda.Stream(device=self.device)
             self._fork_event, self._join_event = ops.new_event(), ops.new_event()
         self._rec = None                 # program being recorded (StepProgram / ListProgram), else None
+        self.replay_failures = 0
         self._plans: Dict[tuple, object] = {}
         self._eager_seen: Dict[tuple, int] = {}
         self.refresh_derived_weights()
@@ -270,9 +290,55 @@ class NativeResNet:
                 self.num_batches_tracked[u.bn] = int(nbt)
         self.refresh_derived_weights()
 
+    def attach_optimizer(self, optimizer) -> None:
+        """Run ``optimizer``'s update per gradient bucket, enqueued right behind the bucket's
+        all-reduce on the communication stream, instead of as one pass over the whole model
+        after backward: when backward ends only the last small bucket and its slice of the
+        update remain.  Backward never reads what the update writes (master weights, momentum,
+        the forward bf16 mirror): data gradients use the transposed weight copies, which are
+        refreshed after the step.  ``optimizer.finish_step()`` is then the caller's only duty."""
+        self._optimizer = optimizer
+        red = self.reducer
+        if optimizer is None:
+            red.set_bucket_hook(None)
+        else:
+            red.set_bucket_hook(lambda lo, hi: optimizer.step_range(lo, hi, red.grad_scale))
+        self._plans.clear()              # a recorded step has the old arrangement baked in
+        self._eager_seen.clear()
+
+    @property
+    def optimizer_in_backward(self) -> bool:
+        return self._optimizer is not None
+
+    def layout_fingerprint(self) -> Tuple[str, int, str, str]:
+        """What every rank of a job must agree on before flat buffers are broadcast over each
+        other: model, element count, per-entry shapes (in flat order), gradient bucket layout."""
+        P = self.params
+        shapes = hashlib.sha256(repr([(k, P.entries[k].shape, P.entries[k].offset) for k in P.order]).encode())
+        buckets = hashlib.sha256(repr(self.buckets).encode())
+        return (self.spec.name if hasattr(self.spec, "name") else type(self.spec).__name__, int(P.total),
+                shapes.hexdigest(), buckets.hexdigest())
+
+    def verify_replicas(self) -> None:
+        """Collective: raise :class:`ReplicaMismatchError` on EVERY rank unless all ranks hold
+        the same parameter layout (DDP's ``_verify_param_shape_across_processes``,
+        ``torch/nn/parallel/distributed.py:862``, behind reference ``train_distributed.py:198``).
+        Broadcasting or reducing flat buffers of different layouts corrupts silently or hangs."""
+        if self.world <= 1:
+            return
+        mine = self.layout_fingerprint() + (int(self.running_mean.numel()),)
+        seen = [None] * self.world
+        dist.all_gather_object(seen, mine, group=self.group)
+        if any(s != seen[0] for s in seen):
+            rows = "\n".join(f"  rank {r}: model={s[0]} elements={s[1]} shapes={s[2][:12]} buckets={s[3][:12]} "
+                             f"bn={s[4]}" for r, s in enumerate(seen))
+            raise ReplicaMismatchError("ranks were built with different models or bucket layouts:\n" + rows)
+
     def broadcast_state(self, src: int = 0) -> None:
-        """Initial replica synchronisation: ONE flat broadcast each for parameters and for
-        BN buffers (DDP does this at construction, ``torch/nn/parallel/distributed.py:864-871``)."""
+        """Initial replica synchronisation: a layout check, then ONE flat broadcast each for
+        parameters and for BN buffers (DDP does this at construction,
+        ``torch/nn/parallel/distributed.py:862-871``)."""
+        self.verify_replicas()
         if self.world > 1:
             dist.broadcast(self.params.p, src=src, group=self.group)
             dist.broadcast(self.params.m, src=src, group=self.group)
@@ -307,19 +373,24 @@ class NativeResNet:
             group = self.group
             self._host(lambda: dist.all_reduce(t, group=group))
 
+    def comm_failed(self) -> bool:
+        """Has an in-kernel statistics exchange of THIS rank timed out?  Reads a pinned host word
+        the kernel writes: no synchronisation, cheap enough for every step; it may lag the GPU
+        by the steps still queued."""
+        return self._xgmi is not None and self._xgmi.peek() != 0
+
+    def raise_on_comm_failure(self) -> None:
+        """Fail fast: a timed-out exchange produced NaN statistics (by construction, never stale
+        memory), so the replica is unusable; the job must end and resume from a checkpoint."""
+        if self.comm_failed():
+            raise CommFailure("the xGMI SyncBatchNorm exchange timed out (a peer rank is gone or stalled beyond "
+                              "runtime.xgmi_timeout_s); this replica's state is poisoned -- resume from the last "
+                              "checkpoint")
+
     def check_comm_health(self) -> bool:
-        """Collective.  False (on every rank) when the xGMI path reported a timeout: it is then
-        dropped for the process group's all-reduce and captured step graphs are discarded."""
-        if self._xgmi is None:
-            return True
-        if self._xgmi.healthy():
-            return True
-        self._xgmi = None
-        self.syncbn_comm = "rccl"
-        self._fused_stats = False
-        self._plans.clear()
-        self._eager_seen.clear()
-        return False
+        """Collective and synchronising: True on every rank iff no rank has seen a timeout.  Run
+        before anything is persisted (a checkpoint must not capture poisoned weights)."""
+        return self._xgmi is None or self._xgmi.healthy()
 
     def _bn_train(self, u: ConvBNSpec, ctx: _UnitCtx, stats, n_local: int) -> None:
         """``stats``: what the conv returned -- a moments tensor, or (fused backends) the pending
@@ -791,6 +862,8 @@ class NativeResNet:
                 self._plans[key] = plan
                 if plan is not None:                 # recording ran the step for real
                     self._count_training_forward()
+                    self.log.info("step replay: recorded a command list for batch %s (%d library calls, %d host "
+                                  "actions)", tuple(img.shape), plan[3].num_calls, plan[3].num_host_actions)
                     return plan[2].clone()
             else:
                 plan = self._capture_plan(img, label)
@@ -821,8 +894,9 @@ class NativeResNet:
                     self._rec = None
                     program.finish()
         except Exception as exc:                     # noqa: BLE001 -- fall back to the eager path
-            import warnings
-            warnings.warn(f"step recording failed ({type(exc).__name__}: {exc}); running eagerly")
+            self.log.warning("step recording failed (%s: %s): this batch signature runs EAGERLY from now on "
+                             "(several times the host cost per step)", type(exc).__name__, exc)
+            self.replay_failures += 1
             self._ctx.clear()
             self._saved.clear()
             self._deferred = None
@@ -832,6 +906,16 @@ class NativeResNet:
 
     MAX_PLANS = 2
     MAX_HOST_ACTIONS = 16
+
+    def active_replay_mode(self) -> str:
+        """``list`` / ``graph`` when at least one batch signature is being replayed, ``off``
+        when replay is disabled, ``pending`` before the first recording, ``eager(failed)``
+        when recording failed."""
+        if not self.hip_graphs:
+            return "eager(failed)" if self.replay_failures else "off"
+        if any(p is not None for p in self._plans.values()):
+            return self.step_replay
+        return "eager(failed)" if self.replay_failures else "pending"
 
     def _capture_plan(self, img: torch.Tensor, label: torch.Tensor):
         from .graphs import StepProgram
@@ -852,8 +936,9 @@ class NativeResNet:
                     self._rec = None
                     program.abort()
         except Exception as exc:                     # noqa: BLE001 -- fall back to the eager path
-            import warnings
-            warnings.warn(f"step-graph capture failed ({type(exc).__name__}: {exc}); running eagerly")
+            self.log.warning("step-graph capture failed (%s: %s): this batch signature runs EAGERLY from now on",
+                             type(exc).__name__, exc)
+            self.replay_failures += 1
             self._ctx.clear()
             self._saved.clear()
             self._deferred = None

@@ -184,7 +184,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_fused_kernel(
         vals[i] = acc_take(acc + i, (size_t)2 * C) * inv_count;
     }
     __syncthreads();
-    if (use_car && !car_exchange_block(car, vals, 2 * C, ctl)) return;
+    // (a timed-out exchange leaves NaN in vals: every output below is then NaN, never stale memory)
+    if (use_car) car_exchange_block(car, vals, 2 * C, ctl);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float s = rmean[c];
         float m0 = vals[c] * inv_world;
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_sums_fused_kernel(const CarDev ca
         if (dgamma) dgamma[c] += s1;
     }
     __syncthreads();
-    if (!car_exchange_block(car, vals, 2 * C, ctl)) return;
+    car_exchange_block(car, vals, 2 * C, ctl);      // after a timeout: NaN sums, status set
     for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sums[i] = vals[i];
 }
 

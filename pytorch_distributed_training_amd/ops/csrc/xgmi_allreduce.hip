@@ -6,7 +6,7 @@ __global__ __launch_bounds__(1024) void car_allreduce_kernel(const CarDev d, flo
     __shared__ unsigned ctl[2];
     for (int i = threadIdx.x; i < n; i += blockDim.x) vals[i] = data[i];
     __syncthreads();
-    if (!car_exchange_block(d, vals, n, ctl)) return;
+    car_exchange_block(d, vals, n, ctl);            // after a timeout: NaN everywhere, status set
     for (int i = threadIdx.x; i < n; i += blockDim.x) data[i] = vals[i];
 }
 
@@ -25,10 +25,23 @@ PDT_API int pdt_car_create(int world, int rank, int max_floats, void** out) {
     e = hipMemset(h->local_base, 0, h->local_bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&h->seq_status, 2 * sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(h->seq_status, 0, 2 * sizeof(unsigned));
+    void* pinned_dev = nullptr;
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->status_pinned, 64, hipHostMallocMapped);
+    if (e == hipSuccess) {
+        *h->status_pinned = 0u;
+        e = hipHostGetDevicePointer(&pinned_dev, h->status_pinned, 0);
+    }
     if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) { (void)hipFree(h->local_base); delete h; return (int)e; }
+    if (e != hipSuccess) {
+        (void)hipFree(h->local_base);
+        if (h->seq_status) (void)hipFree(h->seq_status);
+        if (h->status_pinned) (void)hipHostFree(h->status_pinned);
+        delete h;
+        return (int)e;
+    }
     h->dev.seq = h->seq_status;
     h->dev.status = h->seq_status + 1;
+    h->dev.status_host = static_cast<unsigned*>(pinned_dev);
     h->dev.flags = reinterpret_cast<unsigned*>(h->local_base);
     h->dev.recv = reinterpret_cast<float4*>(static_cast<char*>(h->local_base) + car_recv_offset());
     for (int r = 0; r < CAR_MAX_WORLD; ++r) {
@@ -92,6 +105,14 @@ PDT_API int pdt_car_query(void* handle, unsigned* out2) {
     return (int)hipMemcpy(out2, h->seq_status, 2 * sizeof(unsigned), hipMemcpyDeviceToHost);
 }
 
+// Status word as last written to pinned host memory: no synchronisation, no GPU call.  May lag
+// the device by the kernels still in flight; it never goes back to zero.
+PDT_API int pdt_car_peek(void* handle) {
+    CarHost* h = static_cast<CarHost*>(handle);
+    if (!h || !h->status_pinned) return -2;
+    return (int)*static_cast<volatile unsigned*>(h->status_pinned);
+}
+
 PDT_API int pdt_car_destroy(void* handle) {
     CarHost* h = static_cast<CarHost*>(handle);
     if (!h) return 0;
@@ -100,6 +121,7 @@ PDT_API int pdt_car_destroy(void* handle) {
         if (h->opened[r]) (void)hipIpcCloseMemHandle(h->opened[r]);
     (void)hipFree(h->local_base);
     (void)hipFree(h->seq_status);
+    if (h->status_pinned) (void)hipHostFree(h->status_pinned);
     delete h;
     return 0;
 }

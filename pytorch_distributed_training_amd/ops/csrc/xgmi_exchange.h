@@ -17,9 +17,12 @@
 // The sequence number lives in device memory and is advanced by the kernel itself, which makes
 // the launch replayable from a captured HIP graph.
 //
-// Every wait is bounded (wall-clock timeout): a missing peer sets a status word and the kernel
-// exits, it never spins forever.  The host side verifies the path against the library
-// collective before using it and falls back if anything is off.
+// Every wait is bounded (wall-clock timeout): a missing peer never leaves a kernel spinning.  A
+// timed-out exchange sets a status word in device memory AND in a pinned host word (so the host
+// can poll it every step without synchronising) and returns NaN for every element: whatever is
+// computed from it is poisoned visibly instead of silently wrong, and the trainer aborts the
+// job when it sees the status.  The host side verifies the path against the library collective
+// before using it.
 #pragma once
 #include "common.h"
 
@@ -31,6 +34,7 @@ struct CarDev {
     int max4;                      // capacity of one slot in float4 units
     unsigned* seq;                 // device counter (local, ordinary memory)
     unsigned* status;              // non-zero after a timeout (local)
+    unsigned* status_host;         // the same, in pinned host memory (device-visible address)
     unsigned* flags;               // local flags [2][CAR_MAX_WORLD]
     float4* recv;                  // local receive buffer [2][world][max4]
     unsigned* peer_flags[CAR_MAX_WORLD];
@@ -44,11 +48,12 @@ struct CarHost {
     size_t local_bytes;
     void* opened[CAR_MAX_WORLD];   // IPC mappings to close
     unsigned* seq_status;          // ordinary device memory: [seq, status]
+    unsigned* status_pinned;       // host address of the pinned status word
 };
 
 // Block-wide exchange (any block size, every thread must call it): vals[0..n) in LDS is replaced
 // by its sum over the ranks.  ``ctl`` is two LDS words of scratch.  Returns false (uniformly)
-// after a timeout; vals is then unspecified and the status word is set.
+// after a timeout; vals is then all NaN and both status words are set.
 __device__ __forceinline__ bool car_exchange_block(const CarDev& d, float* vals, int n, unsigned* ctl) {
     const int tid = threadIdx.x, nt = blockDim.x;
     if (tid == 0) {
@@ -57,11 +62,18 @@ __device__ __forceinline__ bool car_exchange_block(const CarDev& d, float* vals,
         unsigned q = __hip_atomic_load(d.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
         __hip_atomic_store(d.seq, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ctl[0] = q;
-        ctl[1] = 0u;
+        // After one timeout the exchange is dead for good (the job is about to be ended by the
+        // host): later calls must not each wait out the full timeout again.
+        ctl[1] = __hip_atomic_load(d.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const unsigned seq = ctl[0];
     const int slot = (int)(seq & 1u);
+    if (ctl[1]) {
+        for (int i = tid; i < n; i += nt) vals[i] = __builtin_nanf("");
+        __syncthreads();
+        return false;
+    }
 
     // 1. push my vector into every rank's slot [slot][my rank].  The exchange buffers are only
     //    ever touched with system-scope (cache-bypassing, write-through) accesses, so no cache
@@ -93,7 +105,12 @@ __device__ __forceinline__ bool car_exchange_block(const CarDev& d, float* vals,
     }
     __syncthreads();
     if (ctl[1]) {                                  // block-uniform: every thread reads the same LDS word
-        if (tid == 0) atomicOr(d.status, 1u);
+        if (tid == 0) {
+            atomicOr(d.status, 1u);
+            __hip_atomic_store(d.status_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        for (int i = tid; i < n; i += nt) vals[i] = __builtin_nanf("");
+        __syncthreads();
         return false;
     }
 

@@ -70,6 +70,7 @@ _sig("pdt_car_open", _vp, _vp)
 _sig("pdt_car_set_timeout_ms", _vp, _i)
 _sig("pdt_car_allreduce", _vp, _vp, _i, _vp)
 _sig("pdt_car_query", _vp, _vp)
+_sig("pdt_car_peek", _vp)
 _sig("pdt_car_destroy", _vp)
 _sig("pdt_conv_igemm", _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
      _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp)

@@ -50,15 +50,27 @@ class FlatSGD:
         return segs
 
     def step(self, grad_scale: float = 1.0) -> None:
+        self.step_range(0, self.params.total, grad_scale)
+        self.finish_step()
+
+    def step_range(self, lo: int, hi: int, grad_scale: float = 1.0) -> None:
+        """The update of the flat elements ``[lo, hi)`` only (one gradient bucket): the engine
+        enqueues it behind that bucket's all-reduce while backward is still running.  A step is
+        complete when every range has been updated and :meth:`finish_step` was called."""
         g = self.param_groups[0]
         P = self.params
-        for start, end, decay in self._segments:
+        for seg_lo, seg_hi, decay in self._segments:
+            start, end = max(lo, seg_lo), min(hi, seg_hi)
+            if start >= end:
+                continue
             pc = None if P.pc is P.p else P.pc[start:end]
             self.ops.sgd_step(
                 P.p[start:end], P.g[start:end], P.m[start:end], pc,
                 g["lr"], g["momentum"], g["weight_decay"] if decay else 0.0, grad_scale,
                 g["nesterov"], g["dampening"], self.steps == 0,
             )
+
+    def finish_step(self) -> None:
         self.steps += 1
 
     def zero_grad(self, set_to_none: bool = True) -> None:  # gradients are zeroed inside step()

@@ -49,8 +49,12 @@ def global_rank(node_rank: int, procs_per_node: int, local_rank: int) -> int:
     return node_rank * procs_per_node + local_rank
 
 
-def pick_device(local_rank: int, backend: str) -> torch.device:
-    if backend != "gloo" and torch.cuda.device_count() > 0 and torch.cuda.is_available():
+def pick_device(local_rank: int, backend: str, device_type: Optional[str] = None) -> torch.device:
+    """``device_type="cuda"`` puts the rank on a GPU whatever the backend (gloo reduces GPU tensors
+    through the host: several ranks can then share one GPU, which is how the multi-rank paths are
+    exercised on a one-GPU machine); by default gloo means the CPU path."""
+    want_gpu = device_type == "cuda" or (device_type is None and backend != "gloo")
+    if want_gpu and torch.cuda.device_count() > 0 and torch.cuda.is_available():
         dev = torch.device("cuda", local_rank % torch.cuda.device_count())
         torch.cuda.set_device(dev)
         return dev
@@ -58,11 +62,11 @@ def pick_device(local_rank: int, backend: str) -> torch.device:
 
 
 def init_distributed(backend: str, dist_url: Optional[str], world_size: int, rank: int, local_rank: int,
-                     procs_per_node: int, timeout_s: int = 1800) -> DistInfo:
+                     procs_per_node: int, timeout_s: int = 1800, device_type: Optional[str] = None) -> DistInfo:
     """Select the device, then join the process group when ``world_size > 1``."""
     if backend == "nccl" and not (torch.cuda.device_count() > 0 and torch.cuda.is_available()):
         backend = "gloo"          # no GPU visible: CPU plumbing path
-    device = pick_device(local_rank, backend)
+    device = pick_device(local_rank, backend, device_type)
     forced = os.environ.get("PDT_FORCE_COLLECTIVES") == "1"      # debug: one-rank group, see GradReducer
     if (world_size > 1 or forced) and not dist.is_initialized():
         kwargs = dict(backend=backend, world_size=world_size, rank=rank,
@@ -85,7 +89,7 @@ def init_distributed(backend: str, dist_url: Optional[str], world_size: int, ran
                     backend=backend, device=device)
 
 
-def init_from_env(backend: str = "nccl", timeout_s: int = 1800) -> DistInfo:
+def init_from_env(backend: str = "nccl", timeout_s: int = 1800, device_type: Optional[str] = None) -> DistInfo:
     """torchrun-style initialisation from ``RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*``."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -93,7 +97,7 @@ def init_from_env(backend: str = "nccl", timeout_s: int = 1800) -> DistInfo:
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(max(torch.cuda.device_count(), 1))))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
-    return init_distributed(backend, "env://", world, rank, local_rank, local_world, timeout_s)
+    return init_distributed(backend, "env://", world, rank, local_rank, local_world, timeout_s, device_type)
 
 
 def shutdown() -> None:
@@ -103,18 +107,6 @@ def shutdown() -> None:
         except Exception:
             pass
         dist.destroy_process_group()
-
-
-def broadcast_flat(t: torch.Tensor, src: int = 0, group=None) -> None:
-    """One broadcast of a flat buffer (initial parameter / buffer synchronisation)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.broadcast(t, src=src, group=group)
-
-
-def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(t, group=group)
-    return t
 
 
 def tensor_fingerprint(t: torch.Tensor) -> torch.Tensor:
@@ -134,10 +126,7 @@ def check_replicas_in_sync(t: torch.Tensor, group=None, rtol: float = 0.0) -> bo
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return True
     fp = tensor_fingerprint(t)
-    if fp.is_cuda:
-        lo, hi = fp.clone(), fp.clone()
-    else:
-        lo, hi = fp.clone(), fp.clone()
+    lo, hi = fp.clone(), fp.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
     tol = rtol * hi.abs().max().item()

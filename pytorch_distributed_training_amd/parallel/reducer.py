@@ -1,4 +1,4 @@
-"""Bucketed gradient all-reduce overlapped with backward.
+"""Bucketed gradient all-reduce overlapped with backward, with a per-bucket follow-up.
 
 Replaces the ``DistributedDataParallel`` C++ ``Reducer`` the upstream trainer relies on
 (reference ``train_distributed.py:198``; bucketing in
@@ -15,15 +15,22 @@ Design for an xGMI mesh of MI355X GPUs:
   over RCCL on a dedicated communication stream that waits on an event recorded on the
   compute stream, so communication of bucket *k* overlaps the backward kernels of the
   layers feeding bucket *k+1*;
+* ``bucket_hook(start, end)`` (optional) is enqueued on the same stream right behind the
+  bucket's all-reduce: the engine puts the fused optimizer update of that slice there, so
+  when backward ends only the last (small) bucket and its slice of the update are still to
+  run -- the whole-model optimizer pass no longer sits serially behind backward.  With a hook
+  the pipeline also runs in a one-rank job (no collective, only the hook on the side stream);
 * the ``1/world_size`` average is not applied here: the fused optimizer kernel folds it
   into its gradient read (``grad_scale``);
+* ``comm_dtype=torch.bfloat16`` halves the bytes on the links: the bucket is rounded to bf16,
+  summed, and written back (``training.grad_allreduce_dtype``);
 * on CPU (gloo) the same code path issues asynchronous all-reduces and waits on the
-  returned work handles.
+  returned work handles (hooks run in bucket order after the waits).
 """
 from __future__ import annotations
 
 import os
-from typing import List, Optional, Tuple
+from typing import Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -31,7 +38,7 @@ import torch.distributed as dist
 
 class GradReducer:
     def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[int, int]], group=None,
-                 overlap: bool = True, compress_bf16: bool = False) -> None:
+                 overlap: bool = True, comm_dtype: Optional[torch.dtype] = None) -> None:
         self.flat = flat_grad
         self.buckets = list(buckets)
         self.group = group
@@ -39,25 +46,38 @@ class GradReducer:
         self.world = dist.get_world_size(group) if initialized else 1
         # PDT_FORCE_COLLECTIVES=1 issues the collectives even in a one-rank group (debug: drives
         # the RCCL / stream / event path on a single GPU).
-        self.enabled = self.world > 1 or (initialized and os.environ.get("PDT_FORCE_COLLECTIVES") == "1")
+        self.collective = self.world > 1 or (initialized and os.environ.get("PDT_FORCE_COLLECTIVES") == "1")
         self.overlap = overlap
-        self.compress_bf16 = compress_bf16
+        self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
         self.is_cuda = flat_grad.is_cuda
+        self.bucket_hook: Optional[Callable[[int, int], None]] = None
         self._next = 0
-        self._pending = []
+        self._pending: list = []
         self._comm_stream: Optional[torch.cuda.Stream] = None
         self._ready_events: List = []
         self._done_events: List = []
-        if self.enabled and self.is_cuda:
-            self._comm_stream = torch.cuda.Stream(device=flat_grad.device) if overlap else None
-            self._ready_events = [torch.cuda.Event() for _ in self.buckets]
-            self._done_events = [torch.cuda.Event() for _ in self.buckets]
-        self.stats = {"launched": 0, "bytes": 0}
+        self._timing: Optional[list] = None
+        self.stats = {"launched": 0, "bytes": 0, "steps": 0}
 
     # ---------------------------------------------------------------------------------
+    @property
+    def enabled(self) -> bool:
+        """Is there anything to do per bucket (a collective, a hook, or both)?"""
+        return self.collective or self.bucket_hook is not None
+
+    def set_bucket_hook(self, hook: Optional[Callable[[int, int], None]]) -> None:
+        self.bucket_hook = hook
+
+    def _ensure_streams(self) -> None:
+        if self.is_cuda and self.overlap and self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=self.flat.device)
+            self._ready_events = [torch.cuda.Event() for _ in self.buckets]
+            self._done_events = [torch.cuda.Event() for _ in self.buckets]
+
     def begin_step(self) -> None:
         self._next = 0
         self._pending.clear()
+        self.stats["steps"] += 1
 
     def mark_ready(self, end_offset: int) -> None:
         """Gradients in ``flat[:end_offset]`` are final: launch every completed bucket."""
@@ -69,31 +89,42 @@ class GradReducer:
 
     def completes_bucket(self, end_offset: int) -> bool:
         """Would :meth:`mark_ready` launch anything?  Lets a caller that records host actions
-        (step-graph capture) skip the offsets that do not finish a bucket."""
+        (step replay) skip the offsets that do not finish a bucket."""
         return self.enabled and self._next < len(self.buckets) and self.buckets[self._next][1] <= end_offset
 
     def _launch(self, idx: int) -> None:
         start, end = self.buckets[idx]
         view = self.flat[start:end]
-        self.stats["launched"] += 1
-        self.stats["bytes"] += view.numel() * 4
-        if self.is_cuda and self._comm_stream is not None:
+        if self.collective:
+            self.stats["launched"] += 1
+            self.stats["bytes"] += view.numel() * (2 if self.comm_dtype is torch.bfloat16 else 4)
+        if self.is_cuda and self.overlap:
+            self._ensure_streams()
             cur = torch.cuda.current_stream(self.flat.device)
             self._ready_events[idx].record(cur)
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(self._ready_events[idx])
-                self._all_reduce(view)
+                if self.collective:
+                    self._all_reduce(view)
+                if self.bucket_hook is not None:
+                    self.bucket_hook(start, end)
                 self._done_events[idx].record(self._comm_stream)
             self._pending.append(idx)
         elif self.is_cuda:
-            self._all_reduce(view)
+            if self.collective:
+                self._all_reduce(view)
+            if self.bucket_hook is not None:
+                self.bucket_hook(start, end)
         else:
-            work = dist.all_reduce(view, group=self.group, async_op=True)
-            self._pending.append(work)
+            work = tmp = None
+            if self.collective:
+                tmp = view.to(self.comm_dtype) if self.comm_dtype is not None else None
+                work = dist.all_reduce(view if tmp is None else tmp, group=self.group, async_op=True)
+            self._pending.append((work, tmp, start, end))
 
     def _all_reduce(self, view: torch.Tensor) -> None:
-        if self.compress_bf16:
-            tmp = view.to(torch.bfloat16)
+        if self.comm_dtype is not None:
+            tmp = view.to(self.comm_dtype)
             dist.all_reduce(tmp, group=self.group)
             view.copy_(tmp)
         else:
@@ -104,14 +135,42 @@ class GradReducer:
         if not self.enabled:
             return
         self.mark_ready(self.flat.numel())
-        if self.is_cuda and self._comm_stream is not None:
+        if self.is_cuda and self.overlap and self._comm_stream is not None:
             cur = torch.cuda.current_stream(self.flat.device)
+            pair = None
+            if self._timing is not None:
+                pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                pair[0].record(cur)
             for idx in self._pending:
                 cur.wait_event(self._done_events[idx])
+            if pair is not None:
+                pair[1].record(cur)
+                self._timing.append(pair)
         elif not self.is_cuda:
-            for work in self._pending:
-                work.wait()
+            for work, tmp, start, end in self._pending:
+                if work is not None:
+                    work.wait()
+                if tmp is not None:
+                    self.flat[start:end].copy_(tmp)
+                if self.bucket_hook is not None:
+                    self.bucket_hook(start, end)
         self._pending.clear()
+
+    # ---------------------------------------------------------------------------------
+    def start_timing(self) -> None:
+        """From now on :meth:`finish` brackets its waits with a timed event pair: the time the
+        compute stream stands still for communication (and the per-bucket hooks) that backward
+        did not hide."""
+        self._timing = []
+
+    def exposed_ms(self) -> Optional[float]:
+        """Mean exposed wait per step since :meth:`start_timing` (synchronises); None if nothing
+        was timed."""
+        if not self._timing:
+            return None
+        torch.cuda.synchronize(self.flat.device)
+        total = sum(a.elapsed_time(b) for a, b in self._timing)
+        return total / len(self._timing)
 
     @property
     def grad_scale(self) -> float:

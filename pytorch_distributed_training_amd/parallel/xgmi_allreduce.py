@@ -107,11 +107,18 @@ class XgmiAllReduce:
             return -1
         return int(out[1])
 
+    def peek(self) -> int:
+        """The status as last written to pinned host memory: no synchronisation, no GPU call; may
+        lag the GPU by the kernels still queued.  Non-zero = a wait timed out (results are NaN)."""
+        if self._h is None:
+            return 0
+        return int(self._lib.pdt_car_peek(self._h))
+
     def healthy(self) -> bool:
         """Collective: True on every rank iff no rank has seen a timeout."""
         return _agree(self.status(), dist.ReduceOp.MAX, self.group, self.device) == 0
 
-    def self_test(self, rounds: int = 48) -> bool:
+    def self_test(self, rounds: int = 48, production_timeout_s: float = 1800.0) -> bool:
         """Collective: compare against the process group's all-reduce over many sizes and
         back-to-back calls (slot reuse, flag reuse); every rank returns the same verdict."""
         # Generous while testing: the first launch on a rank includes loading the code object, and
@@ -142,10 +149,13 @@ class XgmiAllReduce:
         dist.broadcast(ref, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
         ok = ok and bool(torch.equal(probe, ref)) and self.status() == 0
         agreed = _agree(1 if ok else 0, dist.ReduceOp.MIN, self.group, self.device) == 1
-        # In production a rank may legitimately arrive late (rank 0 writing a checkpoint, a slow
-        # loader): wait as a library collective would, but not for ever -- a peer that never
-        # arrives (crashed process) must not leave a kernel spinning on the GPU.
-        self._lib.pdt_car_set_timeout_ms(self._h, int(os.environ.get("PDT_XGMI_TIMEOUT_MS", "20000")))
+        # In production a rank may legitimately arrive late (rank 0 writing a checkpoint, a cold
+        # file cache under a loader): wait as long as a library collective would
+        # (``runtime.xgmi_timeout_s``, by default the process group's own timeout), but not for
+        # ever -- a peer that never arrives must not leave a kernel spinning on the GPU.
+        ms = os.environ.get("PDT_XGMI_TIMEOUT_MS")
+        ms = int(ms) if ms else int(min(max(production_timeout_s, 1.0), 2.0e6) * 1000)
+        self._lib.pdt_car_set_timeout_ms(self._h, ms)
         return agreed
 
     def close(self) -> None:

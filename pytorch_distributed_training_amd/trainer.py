@@ -107,7 +107,7 @@ class Trainer:
                          len(train_ds), len(self.train_loader), len(val_ds), len(self.val_loader))
 
         # ---- model / optimizer / schedule ------------------------------------------------
-        self.engine = build_engine(cfg, self.device, ops_backend=ops_backend)
+        self.engine = build_engine(cfg, self.device, ops_backend=ops_backend, logger=self.logger)
         self.logger.info("Engine: %s", self.engine.describe())
         self.logger.info("Loaded optimizer:\n%s", self.engine.optimizer)
         self.scheduler = get_scheduler(self.engine.optimizer, tr["lr_schedule"], train_iters=tr["train_iters"])
@@ -122,6 +122,7 @@ class Trainer:
         self.meter = ThroughputMeter(self.device)
         self.last_val: Dict[str, float] = {}
         self.history = []          # (iter, loss) pairs logged on this rank (tests read it)
+        self._replay_mode_logged = None
 
     # ------------------------------------------------------------------------------ state
     def _resume(self, path: str) -> None:
@@ -138,6 +139,8 @@ class Trainer:
     def save_checkpoint(self, tag: Optional[str] = None) -> Optional[str]:
         if self.ckpt_dir is None:
             return None
+        if not self.engine.check_health():  # collective: never persist a replica a failed exchange has poisoned
+            raise RuntimeError(f"communication failure detected before the checkpoint of iteration {self.iter + 1}")
         self.engine.prepare_validation()   # collective on every rank (buffer sync without SyncBN)
         path = None
         if self.rank == 0:
@@ -145,6 +148,10 @@ class Trainer:
             ckpt_io.save_checkpoint(path, self.engine.model_state_dict(), self.engine.optimizer_state_dict(),
                                     self.scheduler.state_dict(), self.iter + 1, self.cfg)
             self.logger.info("Saved checkpoint %s", path)
+            keep = int(self.cfg["training"].get("keep_last_checkpoints", 3) or 0)
+            if tag is None and keep > 0:
+                for old in ckpt_io.prune_checkpoints(self.ckpt_dir, keep):
+                    self.logger.info("Removed old checkpoint %s", old)
         if self.world > 1:
             # the other ranks wait here, on the host, rather than inside the next step's first
             # statistics exchange on the GPU
@@ -192,11 +199,11 @@ class Trainer:
             if self.world > 1:
                 dist.all_reduce(loss_val)
             loss_val = loss_val.item() / self.world
-            health = getattr(getattr(self.engine, "model", None), "check_comm_health", None)
-            if health is not None and not health():
-                self.logger.warning("xGMI statistics exchange reported a timeout: switched to the process "
-                                    "group's all-reduce")
             lrs = self.scheduler.get_last_lr()
+            mode = getattr(getattr(self.engine, "model", None), "active_replay_mode", None)
+            if mode is not None and mode() != self._replay_mode_logged:
+                self._replay_mode_logged = mode()
+                self.logger.info("Step replay mode: %s", self._replay_mode_logged)
             self.history.append((self.iter, loss_val))
             if self.rank == 0:
                 perf = self.meter.read()

@@ -30,26 +30,3 @@ def make_deterministic(seed: int, strict: bool = False) -> None:
         torch.cuda.manual_seed_all(seed)
     if strict:
         torch.use_deterministic_algorithms(True, warn_only=True)
-
-
-def rng_state() -> dict:
-    """Snapshot of all RNG states (stored in training checkpoints)."""
-    state = {
-        "python": random.getstate(),
-        "numpy": np.random.get_state(),
-        "torch": torch.get_rng_state(),
-    }
-    if torch.cuda.device_count() > 0 and torch.cuda.is_available():
-        state["cuda"] = torch.cuda.get_rng_state_all()
-    return state
-
-
-def set_rng_state(state: dict) -> None:
-    random.setstate(state["python"])
-    np.random.set_state(state["numpy"])
-    torch.set_rng_state(state["torch"])
-    if "cuda" in state and torch.cuda.device_count() > 0 and torch.cuda.is_available():
-        try:
-            torch.cuda.set_rng_state_all(state["cuda"])
-        except Exception:  # different GPU count on resume: keep the fresh states
-            pass

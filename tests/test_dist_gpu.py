@@ -92,10 +92,134 @@ def test_two_ranks_one_gpu_gloo_syncbn_equivalence(tmp_path):
     x, y = _data()
     loss = single.forward_backward(x.cuda(), y.cuda())
     ref_grads = single.params.g.cpu()
-    cos = torch.nn.functional.cosine_similarity(r0["grads"], ref_grads, dim=0).item()
-    assert cos > 0.97, cos            # bf16: different tile/summation order, same maths
-    assert abs(0.5 * (r0["loss"] + r1["loss"]).item() - loss.item()) < 0.02 * abs(loss.item())
-    assert torch.allclose(r0["rm"], single.running_mean.cpu(), rtol=5e-2, atol=5e-3)
+    # SyncBN over 2 x 8 samples against plain BatchNorm over the 16: every gradient bucket on its
+    # own (a dropped or mis-scaled bucket shows as an error of order one in that bucket; bf16
+    # activations with another summation order give a few 1e-3 .. 1e-2)
+    errs = bucket_errors(r0["grads"], ref_grads, single.buckets)
+    assert max(errs) < BUCKET_TOL, errs
+    assert abs(0.5 * (r0["loss"] + r1["loss"]).item() - loss.item()) < 5e-3 * abs(loss.item())
+    assert torch.allclose(r0["rm"], single.running_mean.cpu(), rtol=2e-2, atol=2e-3)
+
+
+BUCKET_TOL = 4e-2
+
+
+def bucket_errors(grads, ref_grads, buckets):
+    return [((grads[a:b] - ref_grads[a:b]).norm() / (ref_grads[a:b].norm() + 1e-12)).item() for a, b in buckets]
+
+
+def _reducer_worker(rank, world, port, out_dir, backend):
+    """The bucketed reducer alone, on integer-valued gradients (sums are exact in any order):
+    overlapped and in-line launches against one plain all-reduce of the whole buffer."""
+    from pytorch_distributed_training_amd.parallel.reducer import GradReducer
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank, device_id=dev)
+    else:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    n = 3_000_000
+    idx = torch.arange(n, device=dev)
+    mine = ((idx * 7 + rank * 13) % 31 - 15).float()
+    oracle = mine.clone()
+    dist.all_reduce(oracle)
+    cuts = [0, 70_000, 1_000_064, 2_400_000, n]
+    buckets = list(zip(cuts[:-1], cuts[1:]))
+    out = {}
+    for overlap in (True, False):
+        flat = mine.clone()
+        red = GradReducer(flat, buckets, overlap=overlap)
+        hooked = []
+        red.set_bucket_hook(lambda lo, hi: hooked.append((lo, hi)))
+        red.begin_step()
+        red.mark_ready(60_000)           # nothing complete yet
+        red.mark_ready(1_000_064)        # two buckets
+        assert red.completes_bucket(2_400_000) and not red.completes_bucket(2_000_000)
+        red.finish()                     # the rest
+        torch.cuda.synchronize()
+        out[f"equal_{overlap}"] = bool(torch.equal(flat, oracle))
+        out[f"launched_{overlap}"] = red.stats["launched"]
+        out[f"hooked_{overlap}"] = hooked == buckets
+    torch.save(out, os.path.join(out_dir, f"red{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def _run_ranks(fn_call, world, tmp_path, timeout=120, extra_env=None):
+    port = _free_port()
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + os.path.join(ROOT, "tests") + os.pathsep + env.get("PYTHONPATH", "")
+    env.update(extra_env or {})
+    procs = [subprocess.Popen([sys.executable, "-c", f"import test_dist_gpu as t; t.{fn_call.format(rank=r, port=port)}"],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = []
+    try:
+        for pr in procs:
+            out, _ = pr.communicate(timeout=timeout)
+            outs.append(out)
+    except subprocess.TimeoutExpired:
+        for pr in procs:
+            pr.kill()
+        pytest.skip(f"{world} ranks sharing one GPU did not finish within {timeout} s on this host")
+    assert all(pr.returncode == 0 for pr in procs), "\n".join(outs)[-4000:]
+    return outs
+
+
+def test_bucketed_reducer_is_exact_two_ranks_one_gpu(tmp_path):
+    _run_ranks(f"_reducer_worker({{rank}}, 2, {{port}}, {str(tmp_path)!r}, 'gloo')", 2, tmp_path)
+    for r in range(2):
+        res = torch.load(tmp_path / f"red{r}.pt")
+        assert res == {"equal_True": True, "launched_True": 4, "hooked_True": True,
+                       "equal_False": True, "launched_False": 4, "hooked_False": True}, res
+
+
+def test_bucketed_reducer_is_exact_over_rccl_one_rank(tmp_path):
+    """Forced one-rank RCCL group: the communication stream, events and RCCL launches are real."""
+    _run_ranks(f"_reducer_worker({{rank}}, 1, {{port}}, {str(tmp_path)!r}, 'nccl')", 1, tmp_path,
+               extra_env={"PDT_FORCE_COLLECTIVES": "1"})
+    res = torch.load(tmp_path / "red0.pt")
+    assert res["equal_True"] and res["equal_False"] and res["launched_True"] == 4 and res["hooked_True"]
+
+
+def _engine_steps_worker(port, out_dir, syncbn_overlap, replay, steps=5):
+    """One rank, forced collectives over RCCL, the full engine + optimizer for a few steps."""
+    from pytorch_distributed_training_amd.config import validate_cfg
+    from pytorch_distributed_training_amd.engine.engines import build_engine
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=dev)
+    cfg = validate_cfg({
+        "dataset": {"name": "synthetic", "n_classes": 100, "image_size": 64},
+        "training": {"optimizer": {"name": "SGD", "lr": 0.05, "weight_decay": 1e-4, "momentum": 0.9},
+                     "lr_schedule": {"name": "constant"}, "train_iters": steps, "batch_size": 16, "sync_bn": True,
+                     "syncbn_comm": "rccl", "syncbn_overlap": bool(syncbn_overlap), "bucket_cap_mb": 4.0},
+        "model": {"name": "ResNet18"},
+        "runtime": {"step_replay": replay},
+    })
+    torch.manual_seed(5)
+    eng = build_engine(cfg, dev)
+    x, y = _data()
+    x, y = x.cuda(), y.cuda()
+    losses = [float(eng.train_step(x, y)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    m = eng.model
+    torch.save({"losses": losses, "mode": m.active_replay_mode(), "sync_bn": m.sync_bn, "comm": m.syncbn_comm,
+                "launched": m.reducer.stats["launched"], "nb": len(m.buckets), "opt_steps": eng.optimizer.steps,
+                "in_backward": m.optimizer_in_backward, "finite": bool(torch.isfinite(m.params.p).all())},
+               os.path.join(out_dir, f"steps_{int(syncbn_overlap)}_{replay}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("syncbn_overlap", [False, True])
+def test_rccl_syncbn_under_list_replay(tmp_path, syncbn_overlap):
+    """SyncBN over RCCL (with and without the asynchronous backward all-reduce, whose wait() returns
+    True) recorded into a command list and replayed: the replayed steps must run and train."""
+    _run_ranks(f"_engine_steps_worker({{port}}, {str(tmp_path)!r}, {syncbn_overlap}, 'list')", 1, tmp_path,
+               timeout=300, extra_env={"PDT_FORCE_COLLECTIVES": "1"})
+    res = torch.load(tmp_path / f"steps_{int(syncbn_overlap)}_list.pt")
+    assert res["mode"] == "list" and res["sync_bn"] and res["comm"] == "rccl" and res["in_backward"]
+    assert res["launched"] == 5 * res["nb"] and res["opt_steps"] == 5 and res["finite"]
+    assert res["losses"][-1] < res["losses"][0]                  # same batch five times: the loss must fall
 
 
 def _bench(env_extra, launcher):
@@ -122,3 +246,27 @@ def test_forced_collectives_over_rccl_single_rank():
     # (random labels at lr 0.1 are chaotic after a few steps, so losses are only checked for sanity)
     assert 0.0 < forced["config"]["final_loss"] < 1e3 and 0.0 < plain["config"]["final_loss"] < 1e3
     assert forced["value"] > 0.4 * plain["value"]
+
+
+def test_bench_self_launch_two_ranks_share_the_gpu():
+    """``python bench.py --gpus 2`` from a plain shell (no launcher, no RANK / WORLD_SIZE): the script
+    starts its two ranks itself; with one GPU visible they share it (gloo carries the gradient
+    buckets, the SyncBN statistics go through the IPC exchange or gloo)."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3",
+           "--warmup", "3", "--batch", "16"]
+    try:
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    except subprocess.TimeoutExpired:
+        pytest.skip("two ranks sharing one GPU did not finish within 420 s on this host")
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    rec = json.loads(lines[0])
+    cfg = rec["config"]
+    assert rec["n_gpus"] == 2 and cfg["rccl_world"] == 2 and cfg["global_batch"] == 32 and rec["value"] > 0
+    assert cfg["sync_bn_active"] and cfg["syncbn_comm"] in ("xgmi", "rccl") and cfg["comm_healthy"]
+    assert cfg["grad_buckets_reduced_per_step"] == cfg["grad_buckets"] >= 4
+    assert cfg["exposed_comm_ms_per_step"] is not None and cfg["optimizer_in_backward"]

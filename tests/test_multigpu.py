@@ -76,6 +76,7 @@ def _worker(rank, world, port, out_dir, sync_bn, comm):
     torch.cuda.synchronize()
     out = {"loss": loss.float().cpu(), "grads": (eng.params.g * eng.reducer.grad_scale).cpu(),
            "rm": eng.running_mean.cpu(), "launched": eng.reducer.stats["launched"], "n_buckets": len(eng.buckets),
+           "buckets": list(eng.buckets),
            "comm": eng.syncbn_comm if sync_bn else None}
     if local is not None:
         dist.all_reduce(local)
@@ -118,10 +119,62 @@ def test_bucketed_reducer_matches_all_reduce(tmp_path, world):
     assert r0["launched"] == r0["n_buckets"] >= 3
     for r in res[1:]:
         assert torch.equal(r["grads"], r0["grads"])              # replicas agree bit for bit
-    # same local work done twice differs by bf16 rounding order only
-    cos = torch.nn.functional.cosine_similarity(r0["grads"], r0["oracle"], dim=0).item()
-    assert cos > 0.9, cos
+    # the same local work done twice (float atomics in another order), bucket by bucket: a dropped or
+    # mis-scaled bucket is an error of order one in that bucket
+    errs = bucket_errors(r0["grads"], r0["oracle"], r0["buckets"])
+    assert max(errs) < 1e-2, errs
     assert not torch.equal(res[0]["rm"], res[1]["rm"])            # local BatchNorm statistics per rank
+
+
+def bucket_errors(grads, ref_grads, buckets):
+    return [((grads[a:b] - ref_grads[a:b]).norm() / (ref_grads[a:b].norm() + 1e-12)).item() for a, b in buckets]
+
+
+def _reducer_worker(rank, world, port, out_dir):
+    """Integer-valued gradients: the bucketed, overlapped reducer must equal one plain all-reduce
+    of the whole buffer bit for bit, whatever order RCCL sums the ranks in."""
+    from pytorch_distributed_training_amd.parallel.reducer import GradReducer
+    device = torch.device("cuda", rank)
+    torch.cuda.set_device(device)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank,
+                            device_id=device)
+    n = 30_000_000
+    idx = torch.arange(n, device=device)
+    mine = ((idx * 7 + rank * 13) % 31 - 15).float()
+    oracle = mine.clone()
+    dist.all_reduce(oracle)
+    cuts = [0, 262_144, 6_000_000, 12_500_032, 29_000_000, n]
+    buckets = list(zip(cuts[:-1], cuts[1:]))
+    out = {}
+    for overlap in (True, False):
+        flat = mine.clone()
+        red = GradReducer(flat, buckets, overlap=overlap)
+        red.begin_step()
+        for end in cuts[1:-1]:
+            red.mark_ready(end)
+        red.finish()
+        torch.cuda.synchronize()
+        out[f"equal_{overlap}"] = bool(torch.equal(flat, oracle))
+    torch.save(out, os.path.join(out_dir, f"red{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@needs_two
+@pytest.mark.parametrize("world", _worlds())
+def test_reducer_is_exact_against_plain_all_reduce(tmp_path, world):
+    port = _free_port()
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + os.path.join(ROOT, "tests") + os.pathsep + env.get("PYTHONPATH", "")
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    procs = [subprocess.Popen([sys.executable, "-c",
+                               f"import test_multigpu as t; t._reducer_worker({r}, {world}, {port}, {str(tmp_path)!r})"],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = [pr.communicate(timeout=300)[0] for pr in procs]
+    assert all(pr.returncode == 0 for pr in procs), "\n".join(outs)[-4000:]
+    for r in range(world):
+        res = torch.load(os.path.join(tmp_path, f"red{r}.pt"))
+        assert res == {"equal_True": True, "equal_False": True}, (r, res)
 
 
 @needs_two
@@ -137,11 +190,33 @@ def test_syncbn_equals_single_process_batchnorm(tmp_path, world, comm):
     single = _engine(dev, False)
     x, y = _data(world)
     loss = single.forward_backward(x.to(dev), y.to(dev))
-    cos = torch.nn.functional.cosine_similarity(r0["grads"], single.params.g.cpu(), dim=0).item()
-    assert cos > 0.9, cos
+    # SyncBN over world x 8 samples against plain BatchNorm over all of them, bucket by bucket (bf16
+    # activations summed in another order: a few 1e-3 .. 1e-2; a wrong bucket: order one)
+    errs = bucket_errors(r0["grads"], single.params.g.cpu(), r0["buckets"])
+    assert max(errs) < 4e-2, errs
     mean_loss = sum(r["loss"].item() for r in res) / world
-    assert abs(mean_loss - loss.item()) < 0.02 * abs(loss.item())
-    assert torch.allclose(r0["rm"], single.running_mean.cpu(), rtol=5e-2, atol=5e-3)
+    assert abs(mean_loss - loss.item()) < 5e-3 * abs(loss.item())
+    assert torch.allclose(r0["rm"], single.running_mean.cpu(), rtol=2e-2, atol=2e-3)
+
+
+@needs_two
+@pytest.mark.parametrize("world", _worlds())
+def test_bench_from_a_plain_shell(world):
+    """``python bench.py --gpus N`` with no launcher: the script starts its ranks itself."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "4",
+           "--batch", "64"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    cfg = rec["config"]
+    assert rec["n_gpus"] == world and cfg["rccl_world"] == world and cfg["backend"] == "nccl"
+    assert cfg["sync_bn_active"] and cfg["comm_healthy"] and cfg["grad_buckets_reduced_per_step"] == cfg["grad_buckets"]
+    assert cfg["exposed_comm_ms_per_step"] is not None and rec["value"] > 0
 
 
 @needs_two

@@ -95,8 +95,11 @@ def _two_rank_worker(rank, port, provoke_timeout):
             # rank 1 stays away from one call: rank 0's wait must end by itself and be reported
             if rank == 0:
                 x._lib.pdt_car_set_timeout_ms(x._h, 200)
+                out["peek_before"] = x.peek()
                 x.all_reduce(mine)
-                out["status_after_missing_peer"] = x.status()
+                out["status_after_missing_peer"] = x.status()          # synchronises
+                out["peek_after"] = x.peek()                           # the pinned host word, no GPU call
+                out["poisoned"] = bool(torch.isnan(mine).all())        # a defined result, never stale memory
             dist.barrier()
         x.close()
     dist.destroy_process_group()
@@ -136,3 +139,71 @@ def test_missing_peer_times_out_instead_of_hanging():
         pytest.skip("IPC peer mapping is not available between two processes on this host")
     assert r0["self_test"] and r0["status"] == 0
     assert r0["status_after_missing_peer"] == 1, r0
+    assert r0["peek_before"] == 0 and r0["peek_after"] == 1 and r0["poisoned"], r0
+
+
+def _engine_timeout_worker(rank, port):
+    """Two ranks train with SyncBN over the in-kernel exchange; rank 1 stalls before its third step
+    for longer than the exchange's timeout.  Rank 0 must end with CommFailure, not train on."""
+    import time
+    import torch.distributed as dist
+    from pytorch_distributed_training_amd.config import validate_cfg
+    from pytorch_distributed_training_amd.engine.engines import build_engine
+    from pytorch_distributed_training_amd.engine.native_resnet import CommFailure
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=2, rank=rank)
+    cfg = validate_cfg({
+        "dataset": {"name": "synthetic", "n_classes": 100, "image_size": 64},
+        "training": {"optimizer": {"name": "SGD", "lr": 0.05, "momentum": 0.9},
+                     "lr_schedule": {"name": "constant"}, "train_iters": 8, "batch_size": 16, "sync_bn": True,
+                     "syncbn_comm": "xgmi", "bucket_cap_mb": 4.0},
+        "model": {"name": "ResNet18"},
+        "runtime": {"xgmi_timeout_s": 1.0},
+    })
+    torch.manual_seed(5)
+    eng = build_engine(cfg, dev)
+    out = {"comm": eng.model.syncbn_comm, "raised": False, "steps": 0}
+    if eng.model.syncbn_comm == "xgmi":
+        g = torch.Generator().manual_seed(rank)
+        x = torch.randn(8, 3, 64, 64, generator=g).cuda()
+        y = torch.randint(0, 100, (8,), generator=g).cuda()
+        try:
+            for i in range(6):
+                if rank == 1 and i == 2:
+                    torch.cuda.synchronize()
+                    time.sleep(4.0)
+                eng.train_step(x, y)
+                torch.cuda.synchronize()
+                eng.model.raise_on_comm_failure()
+                out["steps"] = i + 1
+        except CommFailure as exc:
+            out["raised"] = True
+            out["message"] = str(exc)
+        out["params_finite"] = bool(torch.isfinite(eng.model.params.p).all())
+    print("RESULT " + json.dumps(out), flush=True)
+    os._exit(0)          # no collective teardown: the peer may be gone, as after a real failure
+
+
+def test_exchange_timeout_ends_training_loudly():
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, "-c", f"import test_xgmi_gpu as t; t._engine_timeout_worker({r}, {port})"],
+                              env=_env(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = []
+    try:
+        for pr in procs:
+            o, _ = pr.communicate(timeout=240)
+            outs.append(o)
+    except subprocess.TimeoutExpired:
+        for pr in procs:
+            pr.kill()
+        pytest.skip("two ranks sharing one GPU did not finish within 240 s on this host")
+    assert all(pr.returncode == 0 for pr in procs), "\n".join(outs)[-4000:]
+    r0, r1 = [json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][-1][7:]) for o in outs]
+    if r0["comm"] != "xgmi":
+        pytest.skip("IPC peer mapping is not available between two processes on this host")
+    # the rank that waited in vain stops with an error within a step of the stall, and what it holds is
+    # recognisably poisoned (NaN), not a plausible-looking wrong model
+    assert r0["raised"] and r0["steps"] <= 3 and "checkpoint" in r0["message"], (r0, r1)
+    assert not r0["params_finite"], r0
