@@ -38,7 +38,7 @@ if ROOT not in sys.path:
 from pytorch_distributed_training_amd.config import validate_cfg  # noqa: E402
 from pytorch_distributed_training_amd.data.loader import DevicePrefetcher  # noqa: E402
 from pytorch_distributed_training_amd.engine.engines import build_engine  # noqa: E402
-from pytorch_distributed_training_amd.parallel import dist_env  # noqa: E402
+from pytorch_distributed_training_amd.parallel import collectives, dist_env  # noqa: E402
 
 
 def synthetic_batches(batch: int, image_size: int, n_classes: int, fmt: str, device: torch.device, mode: str,
@@ -136,6 +136,11 @@ def main() -> int:
     ap.add_argument("--backend", type=str, default="nccl")
     args = ap.parse_args()
 
+    hang_dump = float(os.environ.get("PDT_HANG_DUMP_S", "0") or 0)
+    if hang_dump > 0:                 # debug aid: every thread's Python stack if the run is still going then
+        import faulthandler
+        faulthandler.dump_traceback_later(hang_dump, exit=False)
+
     if args.gpus > 1 and not dist_env.env_launch_detected():
         return self_launch(args.gpus, sys.argv[1:])          # nothing here has touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -196,7 +201,7 @@ def main() -> int:
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if info.distributed:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        collectives.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     exposed = engine.model.reducer.exposed_ms() if native else None
     healthy = engine.check_health()

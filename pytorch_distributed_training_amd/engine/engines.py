@@ -68,7 +68,9 @@ class NativeEngine:
         self.optimizer: FlatSGD = opt_cls(self.model.params, self.ops, no_wd_bn=tr.get("no_wd_bn", False),
                                           **_optimizer_kwargs(cfg))
         self.world = self.model.world
-        if tr.get("optimizer_in_backward", True):
+        import os
+        env = os.environ.get("PDT_OPT_IN_BACKWARD")          # measurement override of the config key
+        if (tr.get("optimizer_in_backward", True) if env is None else env == "1"):
             self.model.attach_optimizer(self.optimizer)
 
     def train_step(self, img: torch.Tensor, label: torch.Tensor) -> torch.Tensor:

@@ -42,6 +42,7 @@ import torch.distributed as dist
 
 from ..models.resnet import BlockSpec, ConvBNSpec, ResNetSpec
 from ..ops import ref as _ref
+from ..parallel import collectives as coll
 from ..parallel.reducer import GradReducer
 from ..utils.profiling import trace_range
 from .params import FlatParams, make_buckets
@@ -340,8 +341,8 @@ class NativeResNet:
         ``torch/nn/parallel/distributed.py:862-871``)."""
         self.verify_replicas()
         if self.world > 1:
-            dist.broadcast(self.params.p, src=src, group=self.group)
-            dist.broadcast(self.params.m, src=src, group=self.group)
+            coll.broadcast(self.params.p, src=src, group=self.group)
+            coll.broadcast(self.params.m, src=src, group=self.group)
             self.sync_buffers(src)
             self.params.refresh_compute()
             self.refresh_derived_weights()
@@ -350,8 +351,8 @@ class NativeResNet:
         """Rank ``src``'s running statistics win (what DDP's per-forward buffer broadcast gives
         upstream without SyncBN).  With SyncBN every rank already holds identical values."""
         if self.world > 1:
-            dist.broadcast(self.running_mean, src=src, group=self.group)
-            dist.broadcast(self.running_var, src=src, group=self.group)
+            coll.broadcast(self.running_mean, src=src, group=self.group)
+            coll.broadcast(self.running_var, src=src, group=self.group)
             self._eval_affine = None
 
     # ------------------------------------------------------------------ BN helpers
@@ -371,7 +372,7 @@ class NativeResNet:
             x.all_reduce(t)                  # an ordinary kernel on the compute stream
         else:
             group = self.group
-            self._host(lambda: dist.all_reduce(t, group=group))
+            self._host(lambda: coll.all_reduce(t, group=group))
 
     def comm_failed(self) -> bool:
         """Has an in-kernel statistics exchange of THIS rank timed out?  Reads a pinned host word
@@ -446,13 +447,13 @@ class NativeResNet:
             group = self.group
             if self._xgmi is not None and self._xgmi.supports(sums):
                 self._xgmi.all_reduce(sums)
-            elif self.syncbn_overlap:
+            elif self.syncbn_overlap and not coll.is_host_staged(sums, group):
                 pending = []
                 self._host(lambda: pending.append(dist.all_reduce(sums, group=group, async_op=True)))
                 self._run_deferred()
                 self._host(lambda: pending.pop().wait())
             else:
-                self._host(lambda: dist.all_reduce(sums, group=group))
+                self._host(lambda: coll.all_reduce(sums, group=group))
         return sums
 
     def _wgrad(self, fn) -> None:

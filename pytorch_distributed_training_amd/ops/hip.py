@@ -530,8 +530,15 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
     return dx
 
 
+# Measurement aid (bench/ablate.sh): PDT_ABLATE=wgrad drops every weight-gradient launch, so the step
+# time that remains is what the critical stream costs without its co-runner.  Results are wrong.
+_ABLATE_WGRAD = "wgrad" in os.environ.get("PDT_ABLATE", "").split(",")
+
+
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, R: int, S: int, stride: int, pad: int, dw: torch.Tensor,
                tile: int = 0, target_blocks: int = 0, atomic_budget_mb: int = 0) -> None:
+    if _ABLATE_WGRAD:
+        return
     x = _bf16c(x, "conv_wgrad x")
     dy = _bf16c(dy, "conv_wgrad dy")
     _f32c(dw, "conv_wgrad dw")

@@ -127,7 +127,8 @@ def check_replicas_in_sync(t: torch.Tensor, group=None, rtol: float = 0.0) -> bo
         return True
     fp = tensor_fingerprint(t)
     lo, hi = fp.clone(), fp.clone()
-    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
-    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    from . import collectives as coll
+    coll.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    coll.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
     tol = rtol * hi.abs().max().item()
     return bool(((hi - lo).abs() <= tol).all().item())

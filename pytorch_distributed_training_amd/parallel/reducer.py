@@ -35,6 +35,8 @@ from typing import Callable, List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
+from . import collectives as coll
+
 
 class GradReducer:
     def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[int, int]], group=None,
@@ -125,10 +127,10 @@ class GradReducer:
     def _all_reduce(self, view: torch.Tensor) -> None:
         if self.comm_dtype is not None:
             tmp = view.to(self.comm_dtype)
-            dist.all_reduce(tmp, group=self.group)
+            coll.all_reduce(tmp, group=self.group)
             view.copy_(tmp)
         else:
-            dist.all_reduce(view, group=self.group)
+            coll.all_reduce(view, group=self.group)
 
     def finish(self) -> None:
         """Launch any remaining bucket and make the compute stream wait for all of them."""

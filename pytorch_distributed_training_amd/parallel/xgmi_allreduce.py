@@ -68,6 +68,12 @@ class XgmiAllReduce:
         my_dev = device.index if device.index is not None else torch.cuda.current_device()
         dist.all_gather_object(info, (bool(ok), socket.gethostname(), bytes(mine.raw), my_dev), group=group)
         ok = all(i[0] for i in info) and len({i[1] for i in info}) == 1
+        # Ranks that SHARE a GPU (a one-GPU rehearsal of a multi-rank job) are refused: a kernel
+        # spinning on a peer's flag depends on the other process's kernels being scheduled next
+        # to it, and with host-blocking collectives (gloo) in the same step that arrangement was
+        # seen to stall for tens of seconds.  The protocol tests opt in explicitly.
+        if ok and len({i[3] for i in info}) < world and os.environ.get("PDT_XGMI_ALLOW_SHARED_GPU") != "1":
+            ok = False
         if ok:       # every peer GPU must be directly addressable from this one (xGMI / PCIe P2P)
             for i in info:
                 if i[3] != my_dev and not torch.cuda.can_device_access_peer(my_dev, i[3]):

@@ -34,6 +34,7 @@ from .data import DevicePrefetcher, build_loader, get_dataset, make_iter_dataloa
 from .engine.engines import build_engine
 from .logging_utils import worker_logger
 from .optim.schedulers import get_scheduler
+from .parallel import collectives as coll
 from .parallel import dist_env
 from .utils.determinism import make_deterministic
 from .utils.metrics import TopKCounter
@@ -197,7 +198,7 @@ class Trainer:
         if self.iter % tr["print_interval"] == 0:
             loss_val = loss.detach().clone().float()
             if self.world > 1:
-                dist.all_reduce(loss_val)
+                coll.all_reduce(loss_val)
             loss_val = loss_val.item() / self.world
             lrs = self.scheduler.get_last_lr()
             mode = getattr(getattr(self.engine, "model", None), "active_replay_mode", None)

@@ -85,7 +85,8 @@ class TopKCounter:
 
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             buf = self.state.to(torch.float32) if self.state.dtype == torch.float64 and self.state.is_cuda else self.state
-            dist.all_reduce(buf, group=group)
+            from ..parallel import collectives as coll
+            coll.all_reduce(buf, group=group)
             if buf is not self.state:
                 self.state.copy_(buf)
 

