@@ -32,7 +32,7 @@ CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libpdt_hip.so")
 ARCH = "gfx950"
-SOURCES = ["elementwise.hip", "reduce.hip", "conv_igemm.hip", "conv_wgrad.hip", "xgmi_allreduce.hip"]
+SOURCES = ["elementwise.hip", "reduce.hip", "conv_igemm.hip", "conv_gemm1x1.hip", "conv_wgrad.hip", "xgmi_allreduce.hip"]
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wno-unused-result"]
 REMARKS = ["-Rpass-analysis=kernel-resource-usage"]
 ASAN_LIB = os.path.join(HERE, "libpdt_hip_asan.so")
@@ -130,7 +130,7 @@ def build(force: bool = False, verbose: bool = False, preset: str = "release") -
             raise RuntimeError(f"hipcc failed for {src}:\n{res.stdout}\n{res.stderr}")
         return obj, parse_resource_remarks(res.stderr)
 
-    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
         results = list(ex.map(compile_one, SOURCES))
     objs = [o for o, _ in results]
     tmp = lib + ".tmp"

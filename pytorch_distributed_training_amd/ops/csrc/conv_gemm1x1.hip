@@ -1,0 +1,475 @@
+// 1x1 convolutions (36 of ResNet-50's 53 convolutions, forward and data gradient) as a streaming GEMM
+// for gfx950 (MI355X):   out[m][n] = sum_k a[row(m)][k] * w[n][k]   (+ epilogue),  bf16 in, fp32
+// accumulate on the matrix cores (v_mfma_f32_16x16x32_bf16), bf16 out.
+//
+// Most of these layers move far more bytes than they multiply (K = 64..512 against 4-13 activation-
+// sized tensors read and written by the epilogue), so the kernel is built around keeping bytes in
+// flight rather than around the MFMA loop:
+//
+//   * operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no
+//     ds_write pass.  The DMA writes 64 lanes x 16 B linearly (8 rows of a 128-byte K slice), so the
+//     bank-conflict swizzle of the fragment reads is applied to the per-lane SOURCE address;
+//   * two LDS stages per workgroup (64 KB for a 128x128 tile, two workgroups per CU).  Workgroups
+//     are persistent and the pipeline runs ACROSS tiles: the first K slice of a workgroup's next tile
+//     is requested before the epilogue of the current one, so with one or two K steps per tile
+//     (K = 64, 128) the loads of tile t+1 fly under the epilogue of tile t;
+//   * the epilogue never touches LDS and needs no barrier: a wave converts its accumulators to bf16
+//     and transposes them between lanes and registers with v_permlane32_swap / v_permlane16_swap
+//     (the MFMA leaves a lane with 4 channels of 4 different 16-channel groups; afterwards it holds
+//     16 CONSECUTIVE channels of one pixel = 32 contiguous bytes), so every epilogue operand
+//     (residual-gradient addend, packed ReLU mask, the BatchNorm input whose backward sums are
+//     being fused) is read and the result written with 16-byte accesses straight from registers;
+//   * all epilogue loads of a wave's 64 x 64 sub-tile are issued before the first one is used.
+//
+// Epilogue options (the same contract as conv_igemm.hip): per-channel BatchNorm statistics of the
+// stored values (forward), "out = (out + addend) * mask" with the addend at full or half resolution
+// and the mask as one bit per element, BatchNorm-backward sums of the layer that consumes the result.
+#include "common.h"
+
+#define G1_NREP 16
+
+struct Gemm1x1Params {
+    const bf16* a;
+    const bf16* w;
+    bf16* out;
+    const bf16* addend;
+    const unsigned char* mask_bits;
+    float* stat_acc;
+    const float* stat_shift;           // forward statistics: per-channel centre (may be null -> 0)
+    const bf16* bstat_y;               // backward sums of the consumer (see conv_igemm.hip)
+    const float* bstat_mean;
+    const float* bstat_scale;
+    const float* bstat_shift;
+    int M, N, K;
+    unsigned a_bytes, w_bytes;
+    int a_stride;                      // elements between two input pixels
+    int Hg, Wg, IS, Hi, Wi;            // GEMM row (b, y, x) on the Hg x Wg grid reads input pixel (y*IS, x*IS)
+    int addend_half;                   // addend is [B][Hg/2][Wg/2][N], present at even (y, x) only
+};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_wave_base, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+
+// (lane group g = lane >> 4) x (register j) transpose of 4 x 4 dwords: afterwards v[j] of group g holds what
+// v[g] of group j held.
+__device__ __forceinline__ void transpose4(unsigned (&v)[4]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        auto r = __builtin_amdgcn_permlane32_swap(v[j], v[j + 2], false, false);
+        v[j] = r[0];
+        v[j + 2] = r[1];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+        auto r = __builtin_amdgcn_permlane16_swap(v[j], v[j + 1], false, false);
+        v[j] = r[0];
+        v[j + 1] = r[1];
+    }
+}
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    union { bf16x2 v; unsigned u; } c;
+    c.v[0] = f2bf(lo);
+    c.v[1] = f2bf(hi);
+    return c.u;
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// Swizzle of the 16-byte chunk index inside an LDS row, chosen so that the ds_read_b128 fragment reads of the
+// 16x16x32 operand layout (lane l: row l & 15, chunk l >> 4) are bank-conflict free for the instruction's
+// 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: 128-byte rows (BK = 64) and 64-byte rows (BK = 32).
+template <int BK>
+__device__ __forceinline__ int g1_swz(int row) {
+    return BK == 64 ? ((row >> 1) & 7) : ((row >> 1) & 2);
+}
+
+template <int BN, int WM, int WN, int BK, int R, bool BSTAT>
+__global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const Gemm1x1Params p) {
+    constexpr int BM = 128, RB = BK * 2;
+    constexpr int CH = BK / 8;                              // 16-byte chunks per LDS row
+    constexpr int RPI = 64 / CH;                            // LDS rows one DMA instruction fills (1 KiB)
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+    static_assert(NI == 4, "a wave owns 64 output channels (4 x 4 lane/register transpose)");
+    static_assert(WM * WN == 4, "four waves");
+    static_assert(R >= 2, "at least two stages");
+    constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_DMA = BM / RPI / 4, B_DMA = BN / RPI / 4;   // DMA instructions per wave and stage
+    constexpr int G = A_DMA + B_DMA;
+    constexpr int KS = BK / 32;
+    static_assert(A_DMA >= 1 && B_DMA >= 1, "every wave takes part in filling both operands");
+
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[R * STAGE + 4 * 2 * 64 * 4];
+    float* red = reinterpret_cast<float*>(smem + R * STAGE);       // [wave][2][64] statistics hand-over
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15, fq = lane >> 4;
+
+    const int n_tiles_n = p.N / BN;
+    const int n_tiles_m = (p.M + BM - 1) / BM;
+    const int nwg = n_tiles_m * n_tiles_n;
+    const int nk = p.K / BK;
+    const int HgWg = p.Hg * p.Wg;
+
+    const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.a, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.w, p.w_bytes);
+
+    auto tile_origin = [&](int v, int& m0, int& n0) {
+        // XCD-aware bijective remap: ids v, v+8, ... run on one XCD; give each XCD a contiguous range of tiles
+        int xcd = v & 7, q = nwg >> 3, r = nwg & 7;
+        int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        m0 = (wgid / n_tiles_n) * BM;
+        n0 = (wgid % n_tiles_n) * BN;
+    };
+
+    // ---- DMA side: a cursor (tile, K step) that runs R-1 steps ahead of the compute cursor, across tiles.
+    // Instruction j of this wave fills LDS rows (wave*DMA + j)*RPI .. of the operand image; lane l lands at
+    // row +l/CH, physical chunk l%CH, which must hold logical chunk (l%CH) ^ swz(row).
+    const int d_row = lane / CH, d_chunk = lane % CH;
+    unsigned voff_a[A_DMA], voff_b[B_DMA];
+    int iv = blockIdx.x, iks = 0, ibuf = 0;                   // gridDim.x <= nwg (launcher)
+    auto setup_issue_tile = [&]() {
+        int m0, n0;
+        tile_origin(iv, m0, n0);
+#pragma unroll
+        for (int j = 0; j < A_DMA; ++j) {
+            const int row = (wave * A_DMA + j) * RPI + d_row;
+            int m = m0 + row;
+            m = m < p.M ? m : p.M - 1;                       // rows past the end are computed and thrown away
+            unsigned pix = (unsigned)m;
+            if (p.IS != 1) {
+                unsigned b = (unsigned)m / (unsigned)HgWg, rem = (unsigned)m - b * (unsigned)HgWg;
+                unsigned y = rem / (unsigned)p.Wg, x = rem - y * (unsigned)p.Wg;
+                pix = (b * (unsigned)p.Hi + y * (unsigned)p.IS) * (unsigned)p.Wi + x * (unsigned)p.IS;
+            }
+            voff_a[j] = (pix * (unsigned)p.a_stride + (unsigned)((d_chunk ^ g1_swz<BK>(row)) * 8)) * 2u;
+        }
+#pragma unroll
+        for (int j = 0; j < B_DMA; ++j) {
+            const int row = (wave * B_DMA + j) * RPI + d_row;
+            voff_b[j] = ((unsigned)(n0 + row) * (unsigned)p.K + (unsigned)((d_chunk ^ g1_swz<BK>(row)) * 8)) * 2u;
+        }
+    };
+    // issue the DMA of the step under the cursor into stage ibuf and advance; false once every step was issued
+    auto issue_next = [&]() -> bool {
+        if (iv >= nwg) return false;
+        unsigned char* As = smem + ibuf * STAGE;
+        unsigned char* Bs = As + A_BYTES;
+        const unsigned soff = (unsigned)iks * (BK * 2);
+#pragma unroll
+        for (int j = 0; j < A_DMA; ++j) dma16(a_rsrc, As + (wave * A_DMA + j) * 1024, voff_a[j], soff);
+#pragma unroll
+        for (int j = 0; j < B_DMA; ++j) dma16(w_rsrc, Bs + (wave * B_DMA + j) * 1024, voff_b[j], soff);
+        ibuf = ibuf + 1 == R ? 0 : ibuf + 1;
+        if (++iks == nk) {
+            iks = 0;
+            iv += gridDim.x;
+            if (iv < nwg) setup_issue_tile();
+        }
+        return true;
+    };
+
+    f32x4 acc[MI][NI];
+    auto compute = [&](int buf) {
+        const unsigned char* As = smem + buf * STAGE;
+        const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            bf16x8 af[MI], bfr[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int row = wn * WTN + j * 16 + frow;
+                bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * RB + (((kk * 4 + fq) ^ g1_swz<BK>(row)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = wm * WTM + i * 16 + frow;
+                af[i] = *reinterpret_cast<const bf16x8*>(As + row * RB + (((kk * 4 + fq) ^ g1_swz<BK>(row)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // per-lane statistics of the 16 channels this lane owns after the transpose (kept across the tiles of a
+    // workgroup while they cover the same channels), and the per-channel constants they need
+    const bool want_stats = p.stat_acc != nullptr;
+    const bool bwd_mask = BSTAT && p.bstat_scale != nullptr;
+    float s0[16], s1[16], ctr[16], msc[BSTAT ? 16 : 1], msh[BSTAT ? 16 : 1];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { s0[k] = 0.f; s1[k] = 0.f; ctr[k] = 0.f; }
+    int stat_n0 = -1;
+
+    // Fold the per-lane partial sums of a channel tile into the replicated accumulator: across the 16 lanes
+    // of a row (same channels, different pixels) by shuffles, across the waves that share the channels
+    // through a small LDS area of its own (the DMA ring stays untouched), then ONE atomic per channel and
+    // workgroup -- hundreds of workgroups finish together and all add into the same few hundred addresses.
+    // Called by every thread of the workgroup at the same point (the condition is workgroup-uniform).
+    auto flush_stats = [&](int n0) {
+        float mine0 = 0.f, mine1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float a = s0[k], b = s1[k];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                a += __shfl_xor(a, off, 64);
+                b += __shfl_xor(b, off, 64);
+            }
+            mine0 = frow == k ? a : mine0;          // lane (fq, frow) keeps channel fq*16 + frow
+            mine1 = frow == k ? b : mine1;
+            s0[k] = 0.f;
+            s1[k] = 0.f;
+        }
+        red[(wave * 2 + 0) * 64 + lane] = mine0;
+        red[(wave * 2 + 1) * 64 + lane] = mine1;
+        __syncthreads();
+        for (int i = tid; i < 2 * BN; i += 256) {
+            const int which = i / BN, c = i % BN;
+            const int wn_c = c / 64;
+            float sum = 0.f;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) sum += red[((m * WN + wn_c) * 2 + which) * 64 + (c & 63)];
+            atomicAdd(p.stat_acc + ((size_t)(blockIdx.x % G1_NREP) * 2 + which) * p.N + n0 + c, sum);
+        }
+        __syncthreads();
+    };
+    auto load_consts = [&](int nb) {
+        const float* center = BSTAT ? p.bstat_mean : p.stat_shift;
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+            f32x4 c = center ? *reinterpret_cast<const f32x4*>(center + nb + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            ctr[k] = c[0]; ctr[k + 1] = c[1]; ctr[k + 2] = c[2]; ctr[k + 3] = c[3];
+            if (BSTAT) {
+                f32x4 a = bwd_mask ? *reinterpret_cast<const f32x4*>(p.bstat_scale + nb + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 b = bwd_mask ? *reinterpret_cast<const f32x4*>(p.bstat_shift + nb + k) : f32x4{1.f, 1.f, 1.f, 1.f};
+                msc[k] = a[0]; msc[k + 1] = a[1]; msc[k + 2] = a[2]; msc[k + 3] = a[3];
+                msh[k] = b[0]; msh[k + 1] = b[1]; msh[k + 2] = b[2]; msh[k + 3] = b[3];
+            }
+        }
+    };
+
+    // ---- pipeline: R stages; at step s the DMA of step s+R-1 is issued (after the barrier that proves every
+    // wave is done with the stage it overwrites) and the wait leaves the R-2 younger groups in flight
+    setup_issue_tile();
+    bool issuing = true;
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i) issuing = issue_next() && issuing;
+    int buf = 0;
+    int v = blockIdx.x;
+    while (true) {
+        int m0, n0;
+        tile_origin(v, m0, n0);               // the tile computed now
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < nk; ++ks) {
+            // This wave's share of the stage has landed: all but the (R-2)*G youngest operations are done, and
+            // the operations issued after this step's group are at least the R-2 groups behind it (epilogue loads
+            // and stores in between only make the wait more conservative).  Once the cursor has run out, fewer
+            // groups follow: drain.
+            if (issuing) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * G) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ... and so has every other wave's; all waves are also done reading the stage refilled next
+            __builtin_amdgcn_s_barrier();
+            if (issuing) issuing = issue_next();
+            compute(buf);
+            buf = buf + 1 == R ? 0 : buf + 1;
+        }
+        const int vn = v + gridDim.x;
+        const bool more = vn < nwg;
+
+        // ---- epilogue, straight from the accumulators ------------------------------------------------------
+        const int nb = n0 + wn * WTN + fq * 16;                       // first of this lane's 16 channels
+        if (want_stats && stat_n0 != n0) {
+            if (stat_n0 >= 0) flush_stats(stat_n0);
+            stat_n0 = n0;
+            load_consts(nb);
+        }
+        // epilogue operands of all MI row groups first, so they are all in flight together
+        int mrow[MI];
+        bool live[MI];
+        u32x4 yv[BSTAT ? MI : 1][2], av[MI][2];
+        unsigned mb[MI];
+        const bool has_addend = p.addend != nullptr, has_mask = p.mask_bits != nullptr;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            mrow[i] = m0 + wm * WTM + i * 16 + frow;
+            live[i] = mrow[i] < p.M;
+            const int m = live[i] ? mrow[i] : p.M - 1;
+            const size_t o = (size_t)m * p.N + nb;
+            if (BSTAT) {
+                const u32x4* yp = reinterpret_cast<const u32x4*>(p.bstat_y + o);
+                yv[i][0] = yp[0];
+                yv[i][1] = yp[1];
+            }
+            if (has_addend) {
+                long long ai = (long long)o;
+                if (p.addend_half) {
+                    unsigned b = (unsigned)m / (unsigned)HgWg, rem = (unsigned)m - b * (unsigned)HgWg;
+                    unsigned y = rem / (unsigned)p.Wg, x = rem - y * (unsigned)p.Wg;
+                    ai = ((y | x) & 1u) ? -1 : (long long)(((size_t)b * (p.Hg >> 1) + (y >> 1)) * (p.Wg >> 1) + (x >> 1)) * p.N + nb;
+                }
+                if (ai >= 0) {
+                    const u32x4* ap = reinterpret_cast<const u32x4*>(p.addend + ai);
+                    av[i][0] = __builtin_nontemporal_load(ap);        // last use of the incoming gradient
+                    av[i][1] = __builtin_nontemporal_load(ap + 1);
+                } else {
+                    av[i][0] = u32x4{0u, 0u, 0u, 0u};
+                    av[i][1] = u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+            if (has_mask) mb[i] = *reinterpret_cast<const unsigned short*>(p.mask_bits + (o >> 3));
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            // bf16 pairs: register j of lane group fq holds channels j*16 + fq*4 + {0,1} / {2,3}
+            unsigned lo[4], hi[4];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                lo[j] = pack2(acc[i][j][0], acc[i][j][1]);
+                hi[j] = pack2(acc[i][j][2], acc[i][j][3]);
+            }
+            transpose4(lo);
+            transpose4(hi);
+            // now register j of lane group g: channels g*16 + j*4 + {0,1} (lo) / {2,3} (hi)
+            float val[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                val[j * 4 + 0] = bf_lo(lo[j]);
+                val[j * 4 + 1] = bf_hi(lo[j]);
+                val[j * 4 + 2] = bf_lo(hi[j]);
+                val[j * 4 + 3] = bf_hi(hi[j]);
+            }
+            if (has_addend) {
+                // the sum is rounded to bf16 like a separate add pass would (and like conv_igemm.hip does)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const unsigned a = av[i][h][d];
+                        const int k = h * 8 + d * 2;
+                        val[k] = bf2f(f2bf(val[k] + bf_lo(a)));
+                        val[k + 1] = bf2f(f2bf(val[k + 1] + bf_hi(a)));
+                    }
+            }
+            if (has_mask) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) val[k] = ((mb[i] >> k) & 1u) ? val[k] : 0.0f;
+            }
+            if (live[i]) {
+                u32x4 o0, o1;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    o0[d] = pack2(val[d * 2], val[d * 2 + 1]);
+                    o1[d] = pack2(val[8 + d * 2], val[8 + d * 2 + 1]);
+                }
+                u32x4* op = reinterpret_cast<u32x4*>(p.out + (size_t)mrow[i] * p.N + nb);
+                __builtin_nontemporal_store(o0, op);
+                __builtin_nontemporal_store(o1, op + 1);
+                if (BSTAT) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const unsigned yy2 = yv[i][h][d];
+                            const int k = h * 8 + d * 2;
+                            float y0 = bf_lo(yy2), y1 = bf_hi(yy2);
+                            float d0 = val[k], d1 = val[k + 1];
+                            if (bwd_mask) {
+                                d0 = (y0 * msc[k] + msh[k]) > 0.0f ? d0 : 0.0f;
+                                d1 = (y1 * msc[k + 1] + msh[k + 1]) > 0.0f ? d1 : 0.0f;
+                            }
+                            s0[k] += d0;
+                            s1[k] += d0 * (y0 - ctr[k]);
+                            s0[k + 1] += d1;
+                            s1[k + 1] += d1 * (y1 - ctr[k + 1]);
+                        }
+                } else if (want_stats) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const float d = val[k] - ctr[k];
+                        s0[k] += d;
+                        s1[k] += d * d;
+                    }
+                }
+            }
+        }
+        if (!more) break;
+        v = vn;
+    }
+    if (want_stats && stat_n0 >= 0) flush_stats(stat_n0);
+}
+
+template <int BN, int WM, int WN, int BK, int R, bool BSTAT>
+static int g1_resident_blocks() {
+    static int cached = 0;
+    if (cached > 0) return cached;
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 512;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm1x1_kernel<BN, WM, WN, BK, R, BSTAT>, 256, 0) != hipSuccess || per_cu <= 0)
+        per_cu = 2;
+    cached = per_cu * cus;
+    return cached;
+}
+
+template <int BN, int WM, int WN, int BK, int R, bool BSTAT>
+static int g1_launch(const Gemm1x1Params& p, hipStream_t s) {
+    long long nwg = (long long)((p.M + 127) / 128) * (p.N / BN);
+    if (nwg <= 0 || nwg > 0x7fffffffLL) return -2;
+    long long grid = g1_resident_blocks<BN, WM, WN, BK, R, BSTAT>();
+    if (grid > nwg) grid = nwg;
+    hipLaunchKernelGGL((gemm1x1_kernel<BN, WM, WN, BK, R, BSTAT>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    return pdt_launch_status();
+}
+
+// tile: 0 = auto (3 when N is a multiple of 128, else 4); 1 = 128 x 128, 2 = 128 x 64 (both: K slices of 32, four-stage
+// ring); 3 = 128 x 128 with K slices of 64 and two stages, 4 = 128 x 64 with K slices of 64 and three stages
+PDT_API int pdt_conv_gemm1x1(const void* a, const void* w, void* out, const void* addend, int addend_half,
+                             const void* mask_bits, float* stat_acc, const float* stat_shift, const void* bstat_y,
+                             const float* bstat_mean, const float* bstat_scale, const float* bstat_shift, long long M,
+                             int N, int K, int a_stride, int Hg, int Wg, int IS, int Hi, int Wi, int tile,
+                             hipStream_t s) {
+    if (M <= 0) return 0;
+    if (M >= 0x7fffffffLL || N < 64 || N % 64 != 0 || K < 64 || K % 64 != 0 || a_stride < K || a_stride % 8 != 0) return -4;
+    if (bstat_y && (!stat_acc || !bstat_mean || (bstat_scale && !bstat_shift))) return -8;
+    if (Hg <= 0 || Wg <= 0 || IS < 1 || M % ((long long)Hg * Wg) != 0) return -5;
+    if (addend && addend_half && ((Hg | Wg) & 1)) return -10;
+    Gemm1x1Params p;
+    p.a = (const bf16*)a; p.w = (const bf16*)w; p.out = (bf16*)out;
+    p.addend = (const bf16*)addend; p.mask_bits = (const unsigned char*)mask_bits;
+    p.stat_acc = stat_acc; p.stat_shift = stat_shift;
+    p.bstat_y = (const bf16*)bstat_y; p.bstat_mean = bstat_mean; p.bstat_scale = bstat_scale; p.bstat_shift = bstat_shift;
+    p.M = (int)M; p.N = N; p.K = K; p.a_stride = a_stride;
+    p.Hg = Hg; p.Wg = Wg; p.IS = IS; p.Hi = Hi; p.Wi = Wi;
+    p.addend_half = (addend && addend_half) ? 1 : 0;
+    {
+        long long images = M / ((long long)Hg * Wg);
+        long long a_b = images * Hi * Wi * a_stride * 2, w_b = (long long)N * K * 2;
+        // offsets are 32-bit and the DMA adds up to K*2 bytes on top of a row's offset
+        if (a_b >= 0x7fff0000LL || w_b >= 0x7fff0000LL) return -7;
+        p.a_bytes = (unsigned)a_b;
+        p.w_bytes = (unsigned)w_b;
+    }
+    if (tile == 0) tile = (N % 128 == 0) ? 3 : 4;          // measured: K slices of 64 beat the deeper ring of 32-slices
+    // a forced 128-wide tile on 64-channel remainders: take the narrow one of the same pipeline
+    if ((tile == 1 || tile == 3) && N % 128 != 0) tile += 1;
+    const bool bs = bstat_y != nullptr;
+    switch (tile) {
+        case 1: return bs ? g1_launch<128, 2, 2, 32, 4, true>(p, s) : g1_launch<128, 2, 2, 32, 4, false>(p, s);
+        case 2: return bs ? g1_launch<64, 4, 1, 32, 4, true>(p, s) : g1_launch<64, 4, 1, 32, 4, false>(p, s);
+        case 3: return bs ? g1_launch<128, 2, 2, 64, 2, true>(p, s) : g1_launch<128, 2, 2, 64, 2, false>(p, s);
+        case 4: return bs ? g1_launch<64, 4, 1, 64, 3, true>(p, s) : g1_launch<64, 4, 1, 64, 3, false>(p, s);
+        default: return -6;
+    }
+}

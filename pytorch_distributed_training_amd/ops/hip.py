@@ -76,6 +76,7 @@ _sig("pdt_conv_igemm", _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _ll, _i, 
      _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp)
 _sig("pdt_conv_igemm_bstats", _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i,
      _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp)
+_sig("pdt_conv_gemm1x1", _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp)
 _sig("pdt_conv_wgrad", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp)
 
 
@@ -302,6 +303,25 @@ def _wgrad(dy, inp, dw, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow, tap
     _check(rc, "pdt_conv_wgrad")
 
 
+# 1x1 convolutions go to the streaming LDS-DMA GEMM (csrc/conv_gemm1x1.hip) when its shape rules hold;
+# PDT_GEMM1X1=0 keeps every convolution on the general implicit-GEMM kernel (A/B measurements).
+_USE_GEMM1X1 = os.environ.get("PDT_GEMM1X1", "1") == "1"
+_G1_TILE = int(os.environ.get("PDT_G1_TILE", "0"))          # measurement override of the 1x1 kernel's tile choice
+
+
+def _gemm1x1_ok(a: torch.Tensor, K: int, N: int, out: torch.Tensor) -> bool:
+    return _USE_GEMM1X1 and K % 64 == 0 and N % 64 == 0 and a.numel() * 2 < 0x7fff0000 and N * K * 2 < 0x7fff0000
+
+
+def _gemm1x1(a, w, out, M, N, K, a_stride, Hg, Wg, IS, Hi, Wi, addend=None, addend_half=False, mask_bits=None,
+             stat_acc=None, stat_shift=None, bstat=None, tile: int = 0) -> None:
+    acc, by, bmean, bscale, bshift = bstat if bstat is not None else (stat_acc, None, None, None, None)
+    rc = _lib.pdt_conv_gemm1x1(_p(a), _p(w), _p(out), _p(addend), int(addend_half), _p(mask_bits), _p(acc), _p(stat_shift),
+                               _p(by), _p(bmean), _p(bscale), _p(bshift), M, N, K, a_stride, Hg, Wg, IS, Hi, Wi,
+                               tile or _G1_TILE, _stream())
+    _check(rc, "pdt_conv_gemm1x1")
+
+
 class PendingStats:
     """Per-channel statistics still sitting in the replicated accumulator a conv epilogue filled:
     consumed either by :func:`bn_finalize_fused` (one kernel: moments, rank exchange, finalize)
@@ -465,10 +485,13 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pa
     y = _out_like(out, (B, Ho, Wo, Co), x.device, "conv_fprop")
     M = B * Ho * Wo
     acc = _accumulator(x.device, Co, acc_slot) if stat_shift is not None else None
-    if tile == 0 and R == S and Hi == Wi:
-        tile = _tile_hint("fprop", B, Ci, Co, R, stride, Hi)
-    _igemm(x, w, y, M, Hi, Wi, Ci, Ci, Ho, Wo, stride, Ho, Wo, 1, 0, 0, Co, Co, R * S * Ci, _fprop_taps(R, S, pad),
-           stat_acc=acc, stat_shift=stat_shift, tile=tile)
+    if R == 1 and S == 1 and pad == 0 and tile <= 0 and _gemm1x1_ok(x, Ci, Co, y):
+        _gemm1x1(x, w, y, M, Co, Ci, Ci, Ho, Wo, stride, Hi, Wi, stat_acc=acc, stat_shift=stat_shift, tile=-tile)
+    else:
+        if tile == 0 and R == S and Hi == Wi:
+            tile = _tile_hint("fprop", B, Ci, Co, R, stride, Hi)
+        _igemm(x, w, y, M, Hi, Wi, Ci, Ci, Ho, Wo, stride, Ho, Wo, 1, 0, 0, Co, Co, R * S * Ci, _fprop_taps(R, S, pad),
+               stat_acc=acc, stat_shift=stat_shift, tile=max(tile, 0))
     if acc is None:
         return y, None
     return y, (PendingStats(acc, Co, M) if defer_stats else _moments_from_acc(acc, Co, M))
@@ -513,6 +536,12 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
                  bshift if recompute else None)
     if bstat is not None and mask_src is not None and not bits:
         raise ValueError("conv_dgrad: with bwd_stats the ReLU mask must be given in packed form (relu_bits)")
+    if R == 1 and S == 1 and pad == 0 and stride == 1 and tile <= 0 and (mask_src is None or bits) \
+            and _gemm1x1_ok(dy, Co, Ci, dx):
+        _gemm1x1(dy, wt, dx, B * Hi * Wi, Ci, Co, Co, Hi, Wi, 1, Hi, Wi, addend=addend, addend_half=addend_half,
+                 mask_bits=mask_src, bstat=bstat, tile=-tile)
+        return dx
+    tile = max(tile, 0)          # (negative values select tiles of the 1x1 kernel only)
     if stride == 1:
         _igemm(dy, wt, dx, B * Hi * Wi, Ho, Wo, Co, Co, Hi, Wi, 1, Hi, Wi, 1, 0, 0, Ci, Ci, R * S * Co,
                _dgrad_taps(R, S, pad, 1, 0, 0), addend=addend, mask=mask_src, tile=tile, bstat=bstat, mask_bits=bits,

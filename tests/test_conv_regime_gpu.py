@@ -47,6 +47,14 @@ MULTI_TILE = [
     (64, 14, 256, 1024, 1, 1, 0, 0),    # automatic choice
     (64, 14, 1024, 256, 1, 1, 0, 5),    # 64x128 tile, 16 K-steps
     (64, 28, 128, 512, 1, 1, 0, 3),     # 64x64 tile: 6272 tiles
+    # the streaming 1x1 kernel (negative tile = its own tile numbering): 128x128 and 128x64 tiles, one to
+    # sixteen K steps per tile, several tiles per workgroup, a channel-tile change inside a workgroup's sequence
+    (16, 56, 64, 256, 1, 1, 0, -1), (16, 56, 64, 384, 1, 1, 0, -1), (64, 28, 128, 512, 1, 1, 0, -1),
+    (16, 56, 256, 64, 1, 1, 0, -2), (64, 14, 1024, 256, 1, 1, 0, -1), (64, 14, 1024, 256, 1, 1, 0, -2),
+    (16, 56, 256, 512, 1, 2, 0, -1), (33, 14, 512, 192, 1, 1, 0, -2), (5, 7, 2048, 512, 1, 1, 0, -1),
+    # the same kernel with K slices of 64: two-stage (128x128) and three-stage (128x64) rings
+    (16, 56, 64, 256, 1, 1, 0, -3), (64, 28, 128, 512, 1, 1, 0, -3), (16, 56, 256, 64, 1, 1, 0, -4),
+    (64, 14, 1024, 256, 1, 1, 0, -3), (33, 14, 512, 192, 1, 1, 0, -4), (3, 7, 64, 64, 1, 1, 0, -2),
 ]
 
 
@@ -99,7 +107,8 @@ def test_dgrad_multi_tile_plain_and_backward_statistics(hip, device, cfg):
         assert torch.allclose(dg1, dg0, rtol=2e-3, atol=tol) and torch.allclose(db1, db0, rtol=2e-3, atol=tol)
 
 
-@pytest.mark.parametrize("B,H,Ci,Co,tile", [(16, 56, 128, 256, 1), (64, 28, 256, 512, 1), (64, 28, 256, 512, 0)])
+@pytest.mark.parametrize("B,H,Ci,Co,tile", [(16, 56, 128, 256, 1), (64, 28, 256, 512, 1), (64, 28, 256, 512, 0),
+                                            (16, 56, 128, 256, -1), (64, 28, 256, 512, -2), (3, 14, 512, 1024, -1)])
 def test_first_conv_dgrad_of_a_downsampling_block(hip, device, B, H, Ci, Co, tile):
     """The data gradient that closes a stride-2 block: 1x1 product + half-resolution addend (the
     projection shortcut's gradient) + packed ReLU mask of the block input + backward sums of the
