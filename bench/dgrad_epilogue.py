@@ -24,6 +24,10 @@ SHAPES = [("layer1.conv1", 256, 64, 56, 2), ("layer2.conv1", 512, 128, 28, 3), (
           ("layer4.conv1", 2048, 512, 7, 2)]
 
 
+# positive: tiles of the general implicit-GEMM kernel; 0: automatic; negative: tiles of the 1x1 streaming kernel
+TILES = (1, 2, 5, 0, -1, -2, -3, -4)
+
+
 def timeit(fn, iters=10, warmup=3):
     for _ in range(warmup):
         fn()
@@ -44,7 +48,7 @@ def main() -> int:
     from pytorch_distributed_training_amd.ops import hip, ref
     dev = torch.device("cuda", 0)
     B = args.batch
-    print(f"{'layer':14s} " + " ".join(f"tile{t:>2d} us" for t in (0, 1, 2, 3, 5)) + "   GB moved   best TB/s")
+    print(f"{'layer':14s} " + " ".join(f"tile{t:>2d} us" for t in TILES) + "   GB moved   best TB/s")
     for name, Ci, Co, H, count in SHAPES:
         dy = torch.randn(B, H, H, Co, device=dev).to(torch.bfloat16)
         w = (torch.randn(Co, 1, 1, Ci, device=dev) * 0.05).to(torch.bfloat16)
@@ -56,7 +60,7 @@ def main() -> int:
         bits.random_(0, 256)
         mean = torch.zeros(Ci, device=dev)
         ts = []
-        for tile in (0, 1, 2, 3, 5):
+        for tile in TILES:
             def fn():
                 g = hip.conv_dgrad(dy, w, wt, (B, H, H, Ci), 1, 1, 1, 0, addend=addend, relu_bits=bits, tile=tile,
                                    bwd_stats=(y, mean, None, None, ref.MASK_NONE))

@@ -48,10 +48,12 @@ def _igemm_entry(name, a):
     return dict(kind=kind, bytes=b, flops=2 * M * N * T * Ci, desc=f"M{M} N{N} K{T}x{Ci}")
 
 
-def _gemm1x1_entry(a):
-    (inp, w, out, addend, addend_half, mask_bits, stat_acc, stat_shift, bstat_y, mean, scale, shift, M, N, K, a_stride, Hg,
-     Wg, IS, Hi, Wi) = a[:21]
-    b = M * a_stride * 2 + N * K * 2 + M * N * 2
+def _conv_dma_entry(a):
+    (inp, w, out, addend, addend_half, mask_bits, stat_acc, stat_shift, bstat_y, mean, scale, shift, M, Hi, Wi, ps, Ci, Hg,
+     Wg, IS, Ho, Wo, OS, oy0, ox0, N, wrow, T) = a[:28]
+    images = M // max(Hg * Wg, 1)
+    in_b = M * ps * 2 if (T == 1 and IS > 1) else images * Hi * Wi * ps * 2
+    b = in_b + N * wrow * 2 + M * N * 2
     if addend:
         b += M * N * 2 // (4 if addend_half else 1)
     if mask_bits:
@@ -59,14 +61,14 @@ def _gemm1x1_entry(a):
     if bstat_y:
         b += M * N * 2
     kind = "igemm+bstat" if bstat_y else ("igemm+addend" if addend else "igemm")
-    return dict(kind=kind, bytes=b, flops=2 * M * N * K, desc=f"M{M} N{N} K1x{K} (1x1 kernel)")
+    return dict(kind=kind, bytes=b, flops=2 * M * N * T * Ci, desc=f"M{M} N{N} K{T}x{Ci} (dma)")
 
 
 def _entry(name, a):
     if name in ("pdt_conv_igemm", "pdt_conv_igemm_bstats"):
         return _igemm_entry(name, a)
-    if name == "pdt_conv_gemm1x1":
-        return _gemm1x1_entry(a)
+    if name == "pdt_conv_dma":
+        return _conv_dma_entry(a)
     if name == "pdt_conv_wgrad":
         dy, inp, dw, M, Hi, Wi, ps, Ci, Hg, Wg, IS, N, ldy, wrow, T = a[:15]
         images = M // max(Hg * Wg, 1)
@@ -113,7 +115,7 @@ def _entry(name, a):
 # library call -> substring of the kernel name it launches (None: no kernel, e.g. a stream wait)
 KERNEL_OF = {
     "pdt_conv_igemm": "igemm_kernel", "pdt_conv_igemm_bstats": "igemm_kernel", "pdt_conv_wgrad": "wgrad_",
-    "pdt_conv_gemm1x1": "gemm1x1_kernel",
+    "pdt_conv_dma": "conv_dma_kernel",
     "pdt_bn_apply": "bn_apply_kernel", "pdt_bn_apply2": "bn_apply2_kernel", "pdt_bn_bwd_elemt": "bn_bwd_elemt_kernel",
     "pdt_bn_bwd_reduce_accum": "bn_bwd_reduce_kernel", "pdt_bn_stats_accum": "bn_stats_kernel",
     "pdt_bn_moments": "bn_moments_kernel", "pdt_bn_finalize": "bn_finalize_kernel",

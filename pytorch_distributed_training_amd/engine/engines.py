@@ -43,6 +43,11 @@ class NativeEngine:
         rt = cfg.get("runtime", {})
         self.device = torch.device(device)
         self.ops = get_ops(self.device, ops_backend)
+        # runtime.deterministic: bit-identical GPU runs (ordered reductions instead of float atomics);
+        # set before anything sizes an accumulator
+        self.deterministic = bool(rt.get("deterministic", False))
+        if hasattr(self.ops, "set_deterministic"):
+            self.ops.set_deterministic(self.deterministic)
         precision = tr.get("precision", "bf16")
         dtype = torch.bfloat16 if (precision == "bf16" and self.device.type == "cuda") else torch.float32
         spec = get_spec(cfg["model"]["name"], cfg["dataset"]["n_classes"])
@@ -116,7 +121,8 @@ class NativeEngine:
         m = self.model
         return (f"NativeEngine(ops={self.ops.name}, dtype={m.dtype}, params={m.params.num_parameters()}, "
                 f"buckets={len(m.buckets)}, sync_bn={m.sync_bn}, syncbn_comm={m.syncbn_comm if m.sync_bn else None}, "
-                f"world={m.world}, step_replay={m.step_replay}, optimizer_in_backward={m.optimizer_in_backward})")
+                f"world={m.world}, step_replay={m.step_replay}, optimizer_in_backward={m.optimizer_in_backward}, "
+                f"deterministic={self.deterministic})")
 
 
 class TorchEngine:

@@ -201,7 +201,9 @@ class NativeResNet:
         # inside HIP graphs, whose parallel branches launch slowly.
         want_ws = os.environ.get("PDT_WGRAD_STREAM", "1" if self.step_replay == "list" else "0") == "1"
         if want_ws and self.device.type == "cuda" and getattr(ops, "name", "") == "hip":
-            self._wgrad_stream = torch.cuda.Stream(device=self.device)
+            # PDT_WGRAD_PRIO: stream priority of the weight-gradient stream (HIP: lower value = served first)
+            prio = os.environ.get("PDT_WGRAD_PRIO")
+            self._wgrad_stream = torch.cuda.Stream(device=self.device, **({"priority": int(prio)} if prio else {}))
             self._fork_event, self._join_event = ops.new_event(), ops.new_event()
         self._rec = None                 # program being recorded (StepProgram / ListProgram), else None
         self.replay_failures = 0

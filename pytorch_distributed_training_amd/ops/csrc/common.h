@@ -111,4 +111,14 @@ __device__ __forceinline__ float wave_max(float v) {
 
 static inline int pdt_launch_status() { return (int)hipGetLastError(); }
 
+// Per-channel partial sums (BatchNorm statistics and their backward counterparts) are added with float atomics into
+// one of ``nrep`` replica rows of an accumulator [nrep][2][C], picked by blockIdx % nrep.  With the default 16 rows
+// several workgroups share a row and their adds arrive in any order: fast, and the low bits differ from run to run.
+// Deterministic mode (pdt_set_deterministic) uses PDT_DET_NREP rows and caps every accumulating grid at that many
+// workgroups: a row then has ONE writer, and the fold adds the rows in index order -- bit-identical results.
+#define PDT_NREP 16
+#define PDT_DET_NREP 1024
+extern int g_pdt_deterministic;
+static inline int pdt_nrep() { return g_pdt_deterministic ? PDT_DET_NREP : PDT_NREP; }
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,18 +1,26 @@
-// 1x1 convolutions (36 of ResNet-50's 53 convolutions, forward and data gradient) as a streaming GEMM
-// for gfx950 (MI355X):   out[m][n] = sum_k a[row(m)][k] * w[n][k]   (+ epilogue),  bf16 in, fp32
-// accumulate on the matrix cores (v_mfma_f32_16x16x32_bf16), bf16 out.
+// Convolution forward / data gradient for gfx950 (MI355X) as a streaming implicit GEMM fed by LDS-DMA:
 //
-// Most of these layers move far more bytes than they multiply (K = 64..512 against 4-13 activation-
-// sized tensors read and written by the epilogue), so the kernel is built around keeping bytes in
-// flight rather than around the MFMA loop:
+//   out[row(m)][n] = sum_{t < T} sum_{c < Ci} in[pix(m, t)][c] * wgt[n][widx(t)*Ci + c]     (+ epilogue)
+//
+// bf16 in, fp32 accumulate on the matrix cores (v_mfma_f32_16x16x32_bf16), bf16 out.  Same geometry
+// contract as conv_igemm.hip (GEMM row = a point of a per-image Hg x Wg grid, a tap table with input
+// offsets, output scatter with stride OS for the parity classes of a strided data gradient); it needs
+// Ci and N to be multiples of 64, which covers every ResNet convolution but the stem and the classifier.
+//
+// Most of these layers move far more bytes than they multiply (1x1 convolutions with K = 64..512
+// against 4-13 activation-sized tensors read and written by the epilogue), so the kernel is built
+// around keeping bytes in flight rather than around the MFMA loop:
 //
 //   * operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no
 //     ds_write pass.  The DMA writes 64 lanes x 16 B linearly (8 rows of a 128-byte K slice), so the
-//     bank-conflict swizzle of the fragment reads is applied to the per-lane SOURCE address;
-//   * two LDS stages per workgroup (64 KB for a 128x128 tile, two workgroups per CU).  Workgroups
-//     are persistent and the pipeline runs ACROSS tiles: the first K slice of a workgroup's next tile
-//     is requested before the epilogue of the current one, so with one or two K steps per tile
-//     (K = 64, 128) the loads of tile t+1 fly under the epilogue of tile t;
+//     bank-conflict swizzle of the fragment reads is applied to the per-lane SOURCE address; taps
+//     that fall into the padding read zeros through the buffer descriptor's range check;
+//   * an R-stage LDS ring per workgroup (two stages of K = 64 for a 128x128 tile: 64 KB, two workgroups
+//     per CU).  Workgroups are persistent and the ring runs ACROSS tiles: the first K slices of a
+//     workgroup's next tile are requested before the epilogue of the current one, so with one or two
+//     K steps per tile (K = 64, 128) the loads of tile t+1 fly under the epilogue of tile t; waits are
+//     counted (s_waitcnt vmcnt(N)) and the barrier is a bare s_barrier, so younger DMA groups and
+//     epilogue stores stay in flight across it;
 //   * the epilogue never touches LDS and needs no barrier: a wave converts its accumulators to bf16
 //     and transposes them between lanes and registers with v_permlane32_swap / v_permlane16_swap
 //     (the MFMA leaves a lane with 4 channels of 4 different 16-channel groups; afterwards it holds
@@ -26,11 +34,11 @@
 // and the mask as one bit per element, BatchNorm-backward sums of the layer that consumes the result.
 #include "common.h"
 
-#define G1_NREP 16
+#define DMA_MAX_TAPS 52
 
-struct Gemm1x1Params {
-    const bf16* a;
-    const bf16* w;
+struct ConvDmaParams {
+    const bf16* in;
+    const bf16* wgt;
     bf16* out;
     const bf16* addend;
     const unsigned char* mask_bits;
@@ -40,11 +48,16 @@ struct Gemm1x1Params {
     const float* bstat_mean;
     const float* bstat_scale;
     const float* bstat_shift;
-    int M, N, K;
-    unsigned a_bytes, w_bytes;
-    int a_stride;                      // elements between two input pixels
-    int Hg, Wg, IS, Hi, Wi;            // GEMM row (b, y, x) on the Hg x Wg grid reads input pixel (y*IS, x*IS)
-    int addend_half;                   // addend is [B][Hg/2][Wg/2][N], present at even (y, x) only
+    int M, N;
+    unsigned in_bytes, wgt_bytes;
+    int Hi, Wi, pix_stride, Ci;        // input image, elements between two pixels, channels per tap
+    int Hg, Wg, IS;                    // GEMM row (b, y, x) on the Hg x Wg grid; tap t reads pixel (y*IS + offy, x*IS + offx)
+    int Ho, Wo, OS, oy0, ox0;          // ... and is written to output pixel (y*OS + oy0, x*OS + ox0)
+    int wrow, T;                       // weight row length (elements), taps
+    int simple_out;                    // output row == GEMM row
+    int addend_half;                   // addend is [B][Ho/2][Wo/2][N], present at even output (y, x) only
+    int nrep;                          // replica rows of the statistics accumulator (see common.h)
+    int taps[DMA_MAX_TAPS];            // offy (int8) | offx (int8) << 8 | widx (uint16) << 16
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -88,7 +101,7 @@ __device__ __forceinline__ int g1_swz(int row) {
 }
 
 template <int BN, int WM, int WN, int BK, int R, bool BSTAT>
-__global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const Gemm1x1Params p) {
+__global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p) {
     constexpr int BM = 128, RB = BK * 2;
     constexpr int CH = BK / 8;                              // 16-byte chunks per LDS row
     constexpr int RPI = 64 / CH;                            // LDS rows one DMA instruction fills (1 KiB)
@@ -114,11 +127,12 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const Gemm1x1Params p) 
     const int n_tiles_n = p.N / BN;
     const int n_tiles_m = (p.M + BM - 1) / BM;
     const int nwg = n_tiles_m * n_tiles_n;
-    const int nk = p.K / BK;
+    const int kc = p.Ci / BK;                 // K steps per tap
+    const int nk = p.T * kc;
     const int HgWg = p.Hg * p.Wg;
 
-    const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.a, p.a_bytes);
-    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.w, p.w_bytes);
+    const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.wgt, p.wgt_bytes);
 
     auto tile_origin = [&](int v, int& m0, int& n0) {
         // XCD-aware bijective remap: ids v, v+8, ... run on one XCD; give each XCD a contiguous range of tiles
@@ -132,8 +146,9 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const Gemm1x1Params p) 
     // Instruction j of this wave fills LDS rows (wave*DMA + j)*RPI .. of the operand image; lane l lands at
     // row +l/CH, physical chunk l%CH, which must hold logical chunk (l%CH) ^ swz(row).
     const int d_row = lane / CH, d_chunk = lane % CH;
-    unsigned voff_a[A_DMA], voff_b[B_DMA];
-    int iv = blockIdx.x, iks = 0, ibuf = 0;                   // gridDim.x <= nwg (launcher)
+    int a_base[A_DMA], a_y[A_DMA], a_x[A_DMA];                 // image base pixel and grid coordinates * IS of this lane's rows
+    unsigned a_sw[A_DMA], voff_b[B_DMA];
+    int iv = blockIdx.x, it = 0, ic = 0, ibuf = 0;            // gridDim.x <= nwg (launcher); cursor = (tile, tap, channel slice)
     auto setup_issue_tile = [&]() {
         int m0, n0;
         tile_origin(iv, m0, n0);
@@ -142,18 +157,17 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const Gemm1x1Params p) 
             const int row = (wave * A_DMA + j) * RPI + d_row;
             int m = m0 + row;
             m = m < p.M ? m : p.M - 1;                       // rows past the end are computed and thrown away
-            unsigned pix = (unsigned)m;
-            if (p.IS != 1) {
-                unsigned b = (unsigned)m / (unsigned)HgWg, rem = (unsigned)m - b * (unsigned)HgWg;
-                unsigned y = rem / (unsigned)p.Wg, x = rem - y * (unsigned)p.Wg;
-                pix = (b * (unsigned)p.Hi + y * (unsigned)p.IS) * (unsigned)p.Wi + x * (unsigned)p.IS;
-            }
-            voff_a[j] = (pix * (unsigned)p.a_stride + (unsigned)((d_chunk ^ g1_swz<BK>(row)) * 8)) * 2u;
+            unsigned b = (unsigned)m / (unsigned)HgWg, rem = (unsigned)m - b * (unsigned)HgWg;
+            unsigned y = rem / (unsigned)p.Wg, x = rem - y * (unsigned)p.Wg;
+            a_base[j] = (int)b * p.Hi * p.Wi;
+            a_y[j] = (int)y * p.IS;
+            a_x[j] = (int)x * p.IS;
+            a_sw[j] = (unsigned)((d_chunk ^ g1_swz<BK>(row)) * 16);
         }
 #pragma unroll
         for (int j = 0; j < B_DMA; ++j) {
             const int row = (wave * B_DMA + j) * RPI + d_row;
-            voff_b[j] = ((unsigned)(n0 + row) * (unsigned)p.K + (unsigned)((d_chunk ^ g1_swz<BK>(row)) * 8)) * 2u;
+            voff_b[j] = ((unsigned)(n0 + row) * (unsigned)p.wrow + (unsigned)((d_chunk ^ g1_swz<BK>(row)) * 8)) * 2u;
         }
     };
     // issue the DMA of the step under the cursor into stage ibuf and advance; false once every step was issued
@@ -161,16 +175,28 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const Gemm1x1Params p) 
         if (iv >= nwg) return false;
         unsigned char* As = smem + ibuf * STAGE;
         unsigned char* Bs = As + A_BYTES;
-        const unsigned soff = (unsigned)iks * (BK * 2);
+        const int tap = p.taps[__builtin_amdgcn_readfirstlane(it)];
+        const int oy = (int)(signed char)(tap & 0xff), ox = (int)(signed char)((tap >> 8) & 0xff), wi = (tap >> 16) & 0xffff;
+        const int c0 = ic * BK;
+        const unsigned wofs = (unsigned)(wi * p.Ci + c0) * 2u;
 #pragma unroll
-        for (int j = 0; j < A_DMA; ++j) dma16(a_rsrc, As + (wave * A_DMA + j) * 1024, voff_a[j], soff);
+        for (int j = 0; j < A_DMA; ++j) {
+            const int iy = a_y[j] + oy, ix = a_x[j] + ox;
+            const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const unsigned off = (unsigned)((a_base[j] + iy * p.Wi + ix) * p.pix_stride + c0) * 2u + a_sw[j];
+            // a tap in the padding: an offset past the descriptor's size makes the DMA write zeros
+            dma16(a_rsrc, As + (wave * A_DMA + j) * 1024, ok ? off : PDT_OOB_OFFSET, 0u);
+        }
 #pragma unroll
-        for (int j = 0; j < B_DMA; ++j) dma16(w_rsrc, Bs + (wave * B_DMA + j) * 1024, voff_b[j], soff);
+        for (int j = 0; j < B_DMA; ++j) dma16(w_rsrc, Bs + (wave * B_DMA + j) * 1024, voff_b[j], wofs);
         ibuf = ibuf + 1 == R ? 0 : ibuf + 1;
-        if (++iks == nk) {
-            iks = 0;
-            iv += gridDim.x;
-            if (iv < nwg) setup_issue_tile();
+        if (++ic == kc) {
+            ic = 0;
+            if (++it == p.T) {
+                it = 0;
+                iv += gridDim.x;
+                if (iv < nwg) setup_issue_tile();
+            }
         }
         return true;
     };
@@ -238,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const Gemm1x1Params p) 
             float sum = 0.f;
 #pragma unroll
             for (int m = 0; m < WM; ++m) sum += red[((m * WN + wn_c) * 2 + which) * 64 + (c & 63)];
-            atomicAdd(p.stat_acc + ((size_t)(blockIdx.x % G1_NREP) * 2 + which) * p.N + n0 + c, sum);
+            atomicAdd(p.stat_acc + ((size_t)(blockIdx.x % p.nrep) * 2 + which) * p.N + n0 + c, sum);
         }
         __syncthreads();
     };
@@ -296,17 +322,28 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const Gemm1x1Params p) 
             load_consts(nb);
         }
         // epilogue operands of all MI row groups first, so they are all in flight together
-        int mrow[MI];
+        size_t oidx[MI];
         bool live[MI];
         u32x4 yv[BSTAT ? MI : 1][2], av[MI][2];
         unsigned mb[MI];
         const bool has_addend = p.addend != nullptr, has_mask = p.mask_bits != nullptr;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            mrow[i] = m0 + wm * WTM + i * 16 + frow;
-            live[i] = mrow[i] < p.M;
-            const int m = live[i] ? mrow[i] : p.M - 1;
-            const size_t o = (size_t)m * p.N + nb;
+            const int mi = m0 + wm * WTM + i * 16 + frow;
+            live[i] = mi < p.M;
+            const int m = live[i] ? mi : p.M - 1;
+            unsigned yo = 0, xo = 0, bimg = 0;
+            size_t orow = (size_t)m;
+            if (!p.simple_out || p.addend_half) {
+                bimg = (unsigned)m / (unsigned)HgWg;
+                const unsigned rem = (unsigned)m - bimg * (unsigned)HgWg;
+                const unsigned y = rem / (unsigned)p.Wg, x = rem - y * (unsigned)p.Wg;
+                yo = y * (unsigned)p.OS + (unsigned)p.oy0;
+                xo = x * (unsigned)p.OS + (unsigned)p.ox0;
+                if (!p.simple_out) orow = ((size_t)bimg * p.Ho + yo) * p.Wo + xo;
+            }
+            const size_t o = orow * p.N + nb;
+            oidx[i] = o;
             if (BSTAT) {
                 const u32x4* yp = reinterpret_cast<const u32x4*>(p.bstat_y + o);
                 yv[i][0] = yp[0];
@@ -314,11 +351,9 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const Gemm1x1Params p) 
             }
             if (has_addend) {
                 long long ai = (long long)o;
-                if (p.addend_half) {
-                    unsigned b = (unsigned)m / (unsigned)HgWg, rem = (unsigned)m - b * (unsigned)HgWg;
-                    unsigned y = rem / (unsigned)p.Wg, x = rem - y * (unsigned)p.Wg;
-                    ai = ((y | x) & 1u) ? -1 : (long long)(((size_t)b * (p.Hg >> 1) + (y >> 1)) * (p.Wg >> 1) + (x >> 1)) * p.N + nb;
-                }
+                if (p.addend_half)
+                    ai = ((yo | xo) & 1u) ? -1
+                                          : (long long)((((size_t)bimg * (p.Ho >> 1) + (yo >> 1)) * (p.Wo >> 1) + (xo >> 1)) * p.N + nb);
                 if (ai >= 0) {
                     const u32x4* ap = reinterpret_cast<const u32x4*>(p.addend + ai);
                     av[i][0] = __builtin_nontemporal_load(ap);        // last use of the incoming gradient
@@ -373,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const Gemm1x1Params p) 
                     o0[d] = pack2(val[d * 2], val[d * 2 + 1]);
                     o1[d] = pack2(val[8 + d * 2], val[8 + d * 2 + 1]);
                 }
-                u32x4* op = reinterpret_cast<u32x4*>(p.out + (size_t)mrow[i] * p.N + nb);
+                u32x4* op = reinterpret_cast<u32x4*>(p.out + oidx[i]);
                 __builtin_nontemporal_store(o0, op);
                 __builtin_nontemporal_store(o1, op + 1);
                 if (BSTAT) {
@@ -417,58 +452,72 @@ static int g1_resident_blocks() {
     int per_cu = 0, dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 512;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm1x1_kernel<BN, WM, WN, BK, R, BSTAT>, 256, 0) != hipSuccess || per_cu <= 0)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_dma_kernel<BN, WM, WN, BK, R, BSTAT>, 256, 0) != hipSuccess || per_cu <= 0)
         per_cu = 2;
     cached = per_cu * cus;
     return cached;
 }
 
 template <int BN, int WM, int WN, int BK, int R, bool BSTAT>
-static int g1_launch(const Gemm1x1Params& p, hipStream_t s) {
+static int g1_launch(const ConvDmaParams& p, hipStream_t s) {
     long long nwg = (long long)((p.M + 127) / 128) * (p.N / BN);
     if (nwg <= 0 || nwg > 0x7fffffffLL) return -2;
     long long grid = g1_resident_blocks<BN, WM, WN, BK, R, BSTAT>();
     if (grid > nwg) grid = nwg;
-    hipLaunchKernelGGL((gemm1x1_kernel<BN, WM, WN, BK, R, BSTAT>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    if (g_pdt_deterministic && grid > p.nrep) grid = p.nrep;      // one statistics row per workgroup
+    hipLaunchKernelGGL((conv_dma_kernel<BN, WM, WN, BK, R, BSTAT>), dim3((unsigned)grid), dim3(256), 0, s, p);
     return pdt_launch_status();
 }
 
 // tile: 0 = auto (3 when N is a multiple of 128, else 4); 1 = 128 x 128, 2 = 128 x 64 (both: K slices of 32, four-stage
 // ring); 3 = 128 x 128 with K slices of 64 and two stages, 4 = 128 x 64 with K slices of 64 and three stages
-PDT_API int pdt_conv_gemm1x1(const void* a, const void* w, void* out, const void* addend, int addend_half,
-                             const void* mask_bits, float* stat_acc, const float* stat_shift, const void* bstat_y,
-                             const float* bstat_mean, const float* bstat_scale, const float* bstat_shift, long long M,
-                             int N, int K, int a_stride, int Hg, int Wg, int IS, int Hi, int Wi, int tile,
-                             hipStream_t s) {
+PDT_API int pdt_conv_dma(const void* in, const void* wgt, void* out, const void* addend, int addend_half,
+                         const void* mask_bits, float* stat_acc, const float* stat_shift, const void* bstat_y,
+                         const float* bstat_mean, const float* bstat_scale, const float* bstat_shift, long long M, int Hi,
+                         int Wi, int pix_stride, int Ci, int Hg, int Wg, int IS, int Ho, int Wo, int OS, int oy0, int ox0,
+                         int N, int wrow, int T, const signed char* offy, const signed char* offx,
+                         const unsigned short* widx, int tile, hipStream_t s) {
+    if (T <= 0 || T > DMA_MAX_TAPS) return -3;
     if (M <= 0) return 0;
-    if (M >= 0x7fffffffLL || N < 64 || N % 64 != 0 || K < 64 || K % 64 != 0 || a_stride < K || a_stride % 8 != 0) return -4;
+    if (M >= 0x7fffffffLL || N < 64 || N % 64 != 0 || Ci < 64 || Ci % 64 != 0 || pix_stride < Ci || pix_stride % 8 != 0 ||
+        wrow < T * Ci)
+        return -4;
     if (bstat_y && (!stat_acc || !bstat_mean || (bstat_scale && !bstat_shift))) return -8;
-    if (Hg <= 0 || Wg <= 0 || IS < 1 || M % ((long long)Hg * Wg) != 0) return -5;
-    if (addend && addend_half && ((Hg | Wg) & 1)) return -10;
-    Gemm1x1Params p;
-    p.a = (const bf16*)a; p.w = (const bf16*)w; p.out = (bf16*)out;
+    if (Hg <= 0 || Wg <= 0 || IS < 1 || OS < 1 || M % ((long long)Hg * Wg) != 0) return -5;
+    if (addend && addend_half && ((Ho | Wo) & 1)) return -10;
+    ConvDmaParams p;
+    p.in = (const bf16*)in; p.wgt = (const bf16*)wgt; p.out = (bf16*)out;
     p.addend = (const bf16*)addend; p.mask_bits = (const unsigned char*)mask_bits;
     p.stat_acc = stat_acc; p.stat_shift = stat_shift;
     p.bstat_y = (const bf16*)bstat_y; p.bstat_mean = bstat_mean; p.bstat_scale = bstat_scale; p.bstat_shift = bstat_shift;
-    p.M = (int)M; p.N = N; p.K = K; p.a_stride = a_stride;
-    p.Hg = Hg; p.Wg = Wg; p.IS = IS; p.Hi = Hi; p.Wi = Wi;
+    p.M = (int)M; p.N = N;
+    p.Hi = Hi; p.Wi = Wi; p.pix_stride = pix_stride; p.Ci = Ci;
+    p.Hg = Hg; p.Wg = Wg; p.IS = IS; p.Ho = Ho; p.Wo = Wo; p.OS = OS; p.oy0 = oy0; p.ox0 = ox0;
+    p.wrow = wrow; p.T = T;
+    p.simple_out = (OS == 1 && oy0 == 0 && ox0 == 0 && Hg == Ho && Wg == Wo) ? 1 : 0;
     p.addend_half = (addend && addend_half) ? 1 : 0;
+    p.nrep = pdt_nrep();
     {
         long long images = M / ((long long)Hg * Wg);
-        long long a_b = images * Hi * Wi * a_stride * 2, w_b = (long long)N * K * 2;
-        // offsets are 32-bit and the DMA adds up to K*2 bytes on top of a row's offset
-        if (a_b >= 0x7fff0000LL || w_b >= 0x7fff0000LL) return -7;
-        p.a_bytes = (unsigned)a_b;
-        p.w_bytes = (unsigned)w_b;
+        long long in_b = images * Hi * Wi * pix_stride * 2, w_b = (long long)N * wrow * 2;
+        // byte offsets are 32-bit; PDT_OOB_OFFSET must stay beyond both tensors
+        if (in_b >= 0x7fff0000LL || w_b >= 0x7fff0000LL) return -7;
+        p.in_bytes = (unsigned)in_b;
+        p.wgt_bytes = (unsigned)w_b;
     }
-    if (tile == 0) tile = (N % 128 == 0) ? 3 : 4;          // measured: K slices of 64 beat the deeper ring of 32-slices
-    // a forced 128-wide tile on 64-channel remainders: take the narrow one of the same pipeline
-    if ((tile == 1 || tile == 3) && N % 128 != 0) tile += 1;
+    for (int i = 0; i < T; ++i)
+        p.taps[i] = ((int)offy[i] & 0xff) | (((int)offx[i] & 0xff) << 8) | ((int)widx[i] << 16);
+    for (int i = T; i < DMA_MAX_TAPS; ++i) p.taps[i] = 0;
     const bool bs = bstat_y != nullptr;
+    // Tiles: 3 = 128 x 128 (2 x 2 waves, K slices of 64, ring of 2), 4 = 128 x 64 (4 x 1 waves, ring of 3).  Tiles 1 / 2
+    // named ring-of-4 pipelines on K slices of 32, which measured slower everywhere; they now select 3 / 4.  A
+    // 128-wide tile is not built with the backward-statistics epilogue (its 16 extra per-lane sums push the kernel
+    // past 256 VGPRs into scratch; those launches are short-K and bandwidth bound, the narrow tile costs nothing).
+    if (tile == 1 || tile == 2) tile += 2;
+    if (tile == 0) tile = (N % 128 == 0) ? 3 : 4;
+    if (tile == 3 && (N % 128 != 0 || bs)) tile = 4;
     switch (tile) {
-        case 1: return bs ? g1_launch<128, 2, 2, 32, 4, true>(p, s) : g1_launch<128, 2, 2, 32, 4, false>(p, s);
-        case 2: return bs ? g1_launch<64, 4, 1, 32, 4, true>(p, s) : g1_launch<64, 4, 1, 32, 4, false>(p, s);
-        case 3: return bs ? g1_launch<128, 2, 2, 64, 2, true>(p, s) : g1_launch<128, 2, 2, 64, 2, false>(p, s);
+        case 3: return g1_launch<128, 2, 2, 64, 2, false>(p, s);
         case 4: return bs ? g1_launch<64, 4, 1, 64, 3, true>(p, s) : g1_launch<64, 4, 1, 64, 3, false>(p, s);
         default: return -6;
     }

@@ -37,7 +37,6 @@
 //     added with float atomics to a replicated accumulator (see reduce.hip).
 #include "common.h"
 
-#define NREP 16
 #define MAX_TAPS 52
 
 struct IgemmParams {
@@ -69,6 +68,7 @@ struct IgemmParams {
     // even coordinates only (the data gradient of a stride-2 1x1 projection shortcut: three quarters of
     // its full-resolution form are zeros that would be written and read back for nothing)
     int addend_half;
+    int nrep;                          // replica rows of the statistics accumulator (see common.h)
     // one 32-bit word per tap: offy (int8) | offx (int8) << 8 | widx (uint16) << 16.  Sub-dword
     // entries would be fetched with VECTOR loads (no scalar byte loads on gfx9), whose waits
     // drain the tile prefetches; a dword indexed by a wave-uniform tap is one s_load_dword.
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256, ((BM * BN == 128 * 64 && !BSTAT) ? 3 : 2)) voi
                     float sum = 0.f;
 #pragma unroll
                     for (int q = 0; q < TR; ++q) sum += red[(q * 2 + which) * BN + col];
-                    atomicAdd(p.stat_acc + ((size_t)(blockIdx.x % NREP) * 2 + which) * p.N + n0 + col, sum);
+                    atomicAdd(p.stat_acc + ((size_t)(blockIdx.x % p.nrep) * 2 + which) * p.N + n0 + col, sum);
                 }
             }
 #pragma unroll
@@ -576,6 +576,7 @@ static int launch_igemm_t(const IgemmParams& p, hipStream_t s) {
     if (nwg <= 0 || nwg > 0x7fffffffLL) return -2;
     long long grid = resident_blocks<BM, BN, BK, WM, WN, BSTAT>();
     if (grid > nwg) grid = nwg;
+    if (g_pdt_deterministic && grid > p.nrep) grid = p.nrep;      // one statistics row per workgroup
     hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WM, WN, BSTAT>), dim3((unsigned)grid), dim3(256), 0, s, p);
     return pdt_launch_status();
 }
@@ -613,6 +614,7 @@ static int conv_igemm_impl(const void* in, const void* wgt, void* out, const voi
     p.Hg = Hg; p.Wg = Wg; p.IS = IS; p.Ho = Ho; p.Wo = Wo; p.OS = OS; p.oy0 = oy0; p.ox0 = ox0;
     p.N = N; p.ldo = ldo; p.wrow = wrow; p.T = T;
     p.addend_half = (addend && addend_half) ? 1 : 0;
+    p.nrep = pdt_nrep();
     if (p.addend_half && ((Ho | Wo) & 1)) return -10;
     p.mask_bits = (mask && mask_bits) ? 1 : 0;
     if (p.mask_bits && ldo != N) return -8;        // the bit image is indexed like a dense [rows][N] tensor

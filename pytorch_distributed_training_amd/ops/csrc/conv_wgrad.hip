@@ -18,6 +18,11 @@
 // tap) and adds its fp32 tile into the flat gradient buffer with float atomics (the buffer
 // is zeroed by the fused optimizer kernel).  Workgroups that share the same dY slice are
 // adjacent after the XCD remap, so re-reads of dY across taps / Cin tiles hit in L2.
+//
+// Deterministic variant (a workspace is passed): slice s STORES its tile into slab s of the workspace
+// (every slab element has exactly one writer) and a second kernel adds the slabs to the gradient in
+// slice order -- no float atomics, bit-identical results from run to run, one more pass over
+// split x output bytes.
 #include "common.h"
 
 #define MAX_TAPS 52
@@ -27,6 +32,8 @@ struct WgradParams {
     const bf16* dy;
     const bf16* in;
     float* dw;
+    float* ws;                         // deterministic mode: [splitk][slab] partial outputs, else NULL
+    long long slab;                    // floats per slab (= N * wrow)
     long long M;
     unsigned in_bytes, dy_bytes;       // tensor sizes for the buffer descriptors
     int Hi, Wi, pix_stride, Ci;
@@ -208,7 +215,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int n = co0 + wm * WTM + i * 16 + fq * 4 + r;
-                if (n < p.N && c < p.Ci) atomicAdd(p.dw + (long long)n * p.wrow + wofs + c, acc[i][j][r]);
+                if (n < p.N && c < p.Ci) {
+                    if (p.ws) p.ws[(long long)split * p.slab + (long long)n * p.wrow + wofs + c] = acc[i][j][r];
+                    else atomicAdd(p.dw + (long long)n * p.wrow + wofs + c, acc[i][j][r]);
+                }
             }
         }
 }
@@ -370,19 +380,46 @@ __global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(const WgradParams p)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int n = co0 + wm * WTM + i * 16 + fq * 4 + r;
-                    if (n < p.N && c < p.Ci) atomicAdd(p.dw + (long long)n * p.wrow + wofs + c, acc[t][i][j][r]);
+                    if (n < p.N && c < p.Ci) {
+                        if (p.ws) p.ws[(long long)split * p.slab + (long long)n * p.wrow + wofs + c] = acc[t][i][j][r];
+                        else atomicAdd(p.dw + (long long)n * p.wrow + wofs + c, acc[t][i][j][r]);
+                    }
                 }
             }
     }
 }
 
+// dw[n][widx(t)*Ci + c] += sum over slices (in slice order) of the slab entries
+__global__ __launch_bounds__(256) void wgrad_fold_kernel(const WgradParams p) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long per_n = (long long)p.T * p.Ci;
+    if (i >= (long long)p.N * per_n) return;
+    int n = (int)(i / per_n);
+    int rem = (int)(i - (long long)n * per_n);
+    int t = rem / p.Ci, c = rem - t * p.Ci;
+    int oy, ox, widx;
+    unpack_tap(p.taps[t], oy, ox, widx);
+    long long off = (long long)n * p.wrow + (long long)widx * p.Ci + c;
+    float s = p.dw[off];
+    for (int k = 0; k < p.splitk; ++k) s += p.ws[(long long)k * p.slab + off];
+    p.dw[off] = s;
+}
+
+static int launch_fold(const WgradParams& p, hipStream_t s) {
+    if (!p.ws) return pdt_launch_status();
+    long long total = (long long)p.N * p.T * p.Ci;
+    hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+    return pdt_launch_status();
+}
+
 template <int BMO, int BNC, int WM, int WN, int TAPS>
-static int launch_wgrad_taps(WgradParams& p, hipStream_t s, int target_blocks) {
+static int launch_wgrad_taps(WgradParams& p, hipStream_t s, int target_blocks, long long ws_slabs) {
     if (p.T % TAPS != 0 || p.Ci > BNC) return -6;
     int n_ct = (p.N + BMO - 1) / BMO * (p.T / TAPS);      // output tiles x tap groups
     long long max_split = (p.M + 2 * BKP - 1) / (2 * BKP);
     long long split = (target_blocks + n_ct - 1) / n_ct;
     if (split > max_split) split = max_split;
+    if (p.ws && split > ws_slabs) split = ws_slabs;
     if (split < 1) split = 1;
     long long rps = (p.M + split - 1) / split;
     rps = (rps + BKP - 1) / BKP * BKP;
@@ -392,11 +429,12 @@ static int launch_wgrad_taps(WgradParams& p, hipStream_t s, int target_blocks) {
     long long nwg = (long long)n_ct * split;
     if (nwg > 0x7fffffffLL) return -2;
     hipLaunchKernelGGL((wgrad_taps_kernel<BMO, BNC, WM, WN, TAPS>), dim3((unsigned)nwg), dim3(256), 0, s, p);
-    return pdt_launch_status();
+    return launch_fold(p, s);
 }
 
 template <int BMO, int BNC, int WM, int WN>
-static int launch_wgrad(WgradParams& p, hipStream_t s, int target_blocks, long long atomic_budget_bytes) {
+static int launch_wgrad(WgradParams& p, hipStream_t s, int target_blocks, long long atomic_budget_bytes,
+                        long long ws_slabs) {
     int n_ct = (p.N + BMO - 1) / BMO;
     int n_cin = (p.Ci + BNC - 1) / BNC;
     long long tiles = (long long)n_ct * n_cin * p.T;
@@ -410,6 +448,7 @@ static int launch_wgrad(WgradParams& p, hipStream_t s, int target_blocks, long l
     long long budget_split = atomic_budget_bytes / (out_bytes > 0 ? out_bytes : 1);
     if (budget_split < 1) budget_split = 1;
     if (split > budget_split) split = budget_split;
+    if (p.ws && split > ws_slabs) split = ws_slabs;
     if (split < 1) split = 1;
     long long rps = (p.M + split - 1) / split;
     rps = (rps + BKP - 1) / BKP * BKP;
@@ -419,22 +458,28 @@ static int launch_wgrad(WgradParams& p, hipStream_t s, int target_blocks, long l
     long long nwg = tiles * split;
     if (nwg > 0x7fffffffLL) return -2;
     hipLaunchKernelGGL((wgrad_kernel<BMO, BNC, WM, WN>), dim3((unsigned)nwg), dim3(256), 0, s, p);
-    return pdt_launch_status();
+    return launch_fold(p, s);
 }
 
 // tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 64x32 (one tap per workgroup), 4 = 128x64,
 //       5 = 64x32 with all 7 taps per workgroup (the stem; auto picks it for T == 7, Ci <= 32),
 //       6 / 7 = 64x64 / 128x64 with three taps (one kernel row) per workgroup, Ci <= 64
+// ws / ws_bytes: workspace of the deterministic variant (NULL: float atomics).  It must stay untouched by other
+// streams until this launch has finished: one workspace per stream that issues weight gradients.
 PDT_API int pdt_conv_wgrad(const void* dy, const void* in, float* dw, long long M, int Hi, int Wi, int pix_stride,
                            int Ci, int Hg, int Wg, int IS, int N, int ldy, int wrow, int T, const signed char* offy,
                            const signed char* offx, const unsigned short* widx, int tile, int target_blocks,
-                           int atomic_budget_mb, hipStream_t s) {
+                           int atomic_budget_mb, float* ws, long long ws_bytes, hipStream_t s) {
     if (T <= 0 || T > MAX_TAPS) return -3;
     if (M <= 0) return 0;
     if (M >= 0x7fffffffLL) return -2;
     if (ldy % 8 != 0 || Ci % 8 != 0 || pix_stride % 4 != 0) return -4;
     WgradParams p;
     p.dy = (const bf16*)dy; p.in = (const bf16*)in; p.dw = dw;
+    p.ws = ws;
+    p.slab = (long long)N * wrow;
+    long long ws_slabs = ws ? ws_bytes / (p.slab * 4) : 0;
+    if (ws && ws_slabs < 1) return -8;
     p.M = M; p.Hi = Hi; p.Wi = Wi; p.pix_stride = pix_stride; p.Ci = Ci;
     {
         long long images = M / ((long long)Hg * Wg);
@@ -456,13 +501,13 @@ PDT_API int pdt_conv_wgrad(const void* dy, const void* in, float* dw, long long 
         else tile = 1;
     }
     switch (tile) {
-        case 1: return launch_wgrad<128, 128, 2, 2>(p, s, target_blocks, budget);
-        case 2: return launch_wgrad<64, 64, 2, 2>(p, s, target_blocks, budget);
-        case 3: return launch_wgrad<64, 32, 2, 2>(p, s, target_blocks, budget);
-        case 4: return launch_wgrad<128, 64, 2, 2>(p, s, target_blocks, budget);
-        case 5: return launch_wgrad_taps<64, 32, 2, 2, 7>(p, s, target_blocks < 2048 ? target_blocks : 768);
-        case 6: return launch_wgrad_taps<64, 64, 2, 2, 3>(p, s, target_blocks);
-        case 7: return launch_wgrad_taps<128, 64, 2, 2, 3>(p, s, target_blocks);
+        case 1: return launch_wgrad<128, 128, 2, 2>(p, s, target_blocks, budget, ws_slabs);
+        case 2: return launch_wgrad<64, 64, 2, 2>(p, s, target_blocks, budget, ws_slabs);
+        case 3: return launch_wgrad<64, 32, 2, 2>(p, s, target_blocks, budget, ws_slabs);
+        case 4: return launch_wgrad<128, 64, 2, 2>(p, s, target_blocks, budget, ws_slabs);
+        case 5: return launch_wgrad_taps<64, 32, 2, 2, 7>(p, s, target_blocks < 2048 ? target_blocks : 768, ws_slabs);
+        case 6: return launch_wgrad_taps<64, 64, 2, 2, 3>(p, s, target_blocks, ws_slabs);
+        case 7: return launch_wgrad_taps<128, 64, 2, 2, 3>(p, s, target_blocks, ws_slabs);
         default: return -6;
     }
 }

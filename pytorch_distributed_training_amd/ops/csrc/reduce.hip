@@ -17,20 +17,32 @@
 #include "common.h"
 #include "xgmi_exchange.h"
 
-#define NREP 16
+#define NREP PDT_NREP
 
-// Fold the NREP replicas of accumulator element i (row stride `stride`) and re-zero them.  All
-// loads are issued before the first store so they overlap (a load/store pair per replica
+int g_pdt_deterministic = 0;
+
+// Deterministic mode: one accumulator row per workgroup, ordered folds, weight gradients through per-slice slabs
+// (conv_wgrad.hip) -- two runs on the same inputs give bit-identical results, at a cost in speed.
+PDT_API int pdt_set_deterministic(int on) {
+    g_pdt_deterministic = on ? 1 : 0;
+    return 0;
+}
+PDT_API int pdt_accumulator_rows() { return pdt_nrep(); }
+
+// Fold the nrep replicas of accumulator element i (row stride `stride`) in index order and re-zero them.  All
+// loads of a group of 16 are issued before the first store so they overlap (a load/store pair per replica
 // serialises on the load latency).
-__device__ __forceinline__ float acc_take(float* p, size_t stride) {
-    float v[NREP];
-#pragma unroll
-    for (int r = 0; r < NREP; ++r) v[r] = p[(size_t)r * stride];
+__device__ __forceinline__ float acc_take(float* p, size_t stride, int nrep) {
     float s = 0.0f;
+    for (int r0 = 0; r0 < nrep; r0 += NREP) {
+        float v[NREP];
 #pragma unroll
-    for (int r = 0; r < NREP; ++r) {
-        s += v[r];
-        p[(size_t)r * stride] = 0.0f;
+        for (int r = 0; r < NREP; ++r) v[r] = p[(size_t)(r0 + r) * stride];
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) {
+            s += v[r];
+            p[(size_t)(r0 + r) * stride] = 0.0f;
+        }
     }
     return s;
 }
@@ -57,7 +69,8 @@ static inline ColGeom col_geom(long long rows, int C) {
     g.cv = cvec < 32 ? cvec : 32;
     g.rl = 256 / g.cv;
     g.slabs = cvec / g.cv;
-    long long target_blocks = 2048 / g.slabs;
+    // (deterministic mode: at most one workgroup per accumulator row)
+    long long target_blocks = (g_pdt_deterministic ? PDT_DET_NREP : 2048) / g.slabs;
     long long rpb = (rows + target_blocks - 1) / target_blocks;
     long long min_rpb = (long long)g.rl * 8;
     if (rpb < min_rpb) rpb = min_rpb;
@@ -70,7 +83,8 @@ static inline ColGeom col_geom(long long rows, int C) {
 // Reduce the per-thread 2x8 partials over the row lanes of the block and add them to the
 // replica accumulator.  acc0/acc1: per-thread partial sums for its 8 channels.
 __device__ __forceinline__ void block_col_reduce_atomic(float (&a0)[8], float (&a1)[8], int cv, int rl, int col_lane,
-                                                        int row_lane, int c_base, int C, float* __restrict__ acc) {
+                                                        int row_lane, int c_base, int C, float* __restrict__ acc,
+                                                        int nrep) {
     __shared__ float red[2][256][8 + 1];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { red[0][threadIdx.x][k] = a0[k]; red[1][threadIdx.x][k] = a1[k]; }
@@ -83,7 +97,7 @@ __device__ __forceinline__ void block_col_reduce_atomic(float (&a0)[8], float (&
         int cl = col / 8, k = col % 8;
         float s = 0.0f;
         for (int r = 0; r < rl; ++r) s += red[which][r * cv + cl][k];
-        float* dst = acc + ((size_t)(blockIdx.x % NREP) * 2 + which) * C + c_base + col;
+        float* dst = acc + ((size_t)(blockIdx.x % nrep) * 2 + which) * C + c_base + col;
         atomicAdd(dst, s);
     }
 }
@@ -91,7 +105,7 @@ __device__ __forceinline__ void block_col_reduce_atomic(float (&a0)[8], float (&
 // ---- BN statistics: acc += [sum(y - s), sum((y - s)^2)] -----------------------------------
 __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16* __restrict__ y, const float* __restrict__ shift,
                                                         float* __restrict__ acc, long long rows, int C, int cv,
-                                                        int rl, int slabs, int rows_per_block) {
+                                                        int rl, int slabs, int rows_per_block, int nrep) {
     int slab = blockIdx.x % slabs;
     int chunk = blockIdx.x / slabs;
     int col_lane = threadIdx.x % cv;
@@ -113,27 +127,27 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16* __restrict__ 
             a1[k] += d * d;
         }
     }
-    block_col_reduce_atomic(a0, a1, cv, rl, col_lane, row_lane, c_base, C, acc);
+    block_col_reduce_atomic(a0, a1, cv, rl, col_lane, row_lane, c_base, C, acc, nrep);
 }
 
 PDT_API int pdt_bn_stats_accum(const void* y, const float* shift, float* acc, long long rows, int C, hipStream_t s) {
     if (C % 8 != 0 || (C / 8 < 32 ? 256 % (C / 8) != 0 : (C / 8) % 32 != 0)) return -1;
     ColGeom g = col_geom(rows, C);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(g.slabs * g.row_chunks), dim3(256), 0, s, (const bf16*)y, shift, acc, rows,
-                       C, g.cv, g.rl, g.slabs, g.rows_per_block);
+                       C, g.cv, g.rl, g.slabs, g.rows_per_block, pdt_nrep());
     return pdt_launch_status();
 }
 
 // ---- replicas -> shifted moments [E[y-s], E[(y-s)^2]] ; zero the replicas -------------------
 __global__ __launch_bounds__(256) void bn_moments_kernel(float* __restrict__ acc, float* __restrict__ moments, int C,
-                                                          float inv_count) {
+                                                          float inv_count, int nrep) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 2*C
     if (i >= 2 * C) return;
-    moments[i] = acc_take(acc + i, (size_t)2 * C) * inv_count;
+    moments[i] = acc_take(acc + i, (size_t)2 * C, nrep) * inv_count;
 }
 
 PDT_API int pdt_bn_moments(float* acc, float* moments, int C, float inv_count, hipStream_t s) {
-    hipLaunchKernelGGL(bn_moments_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, acc, moments, C, inv_count);
+    hipLaunchKernelGGL(bn_moments_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, acc, moments, C, inv_count, pdt_nrep());
     return pdt_launch_status();
 }
 
@@ -177,11 +191,11 @@ __global__ __launch_bounds__(1024) void bn_finalize_fused_kernel(
     const CarDev car, int use_car, float* __restrict__ acc, float inv_count, float inv_world,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
     float* __restrict__ rvar, float momentum, float eps, float unbias, float* __restrict__ scale,
-    float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out, int C) {
+    float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out, int C, int nrep) {
     __shared__ float vals[CAR_MAX_FLOATS];
     __shared__ unsigned ctl[2];
     for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
-        vals[i] = acc_take(acc + i, (size_t)2 * C) * inv_count;
+        vals[i] = acc_take(acc + i, (size_t)2 * C, nrep) * inv_count;
     }
     __syncthreads();
     // (a timed-out exchange leaves NaN in vals: every output below is then NaN, never stale memory)
@@ -220,7 +234,7 @@ PDT_API int pdt_bn_finalize_fused(void* car, float* acc, float inv_count, float 
     CarDev dev = h ? h->dev : CarDev{};
     int threads = 2 * C >= 1024 ? 1024 : (2 * C >= 256 ? 2 * C : 256);     // one accumulator element per thread
     hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3(1), dim3(threads), 0, s, dev, h ? 1 : 0, acc, inv_count, inv_world,
-                       gamma, beta, rmean, rvar, momentum, eps, unbias, scale, shift, mean_out, invstd_out, C);
+                       gamma, beta, rmean, rvar, momentum, eps, unbias, scale, shift, mean_out, invstd_out, C, pdt_nrep());
     return pdt_launch_status();
 }
 
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restri
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift, float* __restrict__ acc,
                                                              long long rows, int C, int cv, int rl, int slabs,
-                                                             int rows_per_block) {
+                                                             int rows_per_block, int nrep) {
     int slab = blockIdx.x % slabs;
     int chunk = blockIdx.x / slabs;
     int col_lane = threadIdx.x % cv;
@@ -286,7 +300,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restri
             a1[k] += dy * (yy - mu[k]);
         }
     }
-    block_col_reduce_atomic(a0, a1, cv, rl, col_lane, row_lane, c_base, C, acc);
+    block_col_reduce_atomic(a0, a1, cv, rl, col_lane, row_lane, c_base, C, acc, nrep);
 }
 
 PDT_API int pdt_bn_bwd_reduce_accum(const void* g, const void* y, const void* msrc, const float* mean,
@@ -296,7 +310,7 @@ PDT_API int pdt_bn_bwd_reduce_accum(const void* g, const void* y, const void* ms
     ColGeom gm = col_geom(rows, C);
     dim3 grid(gm.slabs * gm.row_chunks), block(256);
 #define LAUNCH(M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M>), grid, block, 0, s, (const bf16*)g, (const bf16*)y, \
-                                     (const bf16*)msrc, mean, scale, shift, acc, rows, C, gm.cv, gm.rl, gm.slabs, gm.rows_per_block)
+                                     (const bf16*)msrc, mean, scale, shift, acc, rows, C, gm.cv, gm.rl, gm.slabs, gm.rows_per_block, pdt_nrep())
     if (mode == MASK_NONE) LAUNCH(MASK_NONE);
     else if (mode == MASK_TENSOR) LAUNCH(MASK_TENSOR);
     else LAUNCH(MASK_RECOMPUTE);
@@ -311,7 +325,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(
     const bf16* __restrict__ dout, const unsigned char* __restrict__ idx, const bf16* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ scale, const float* __restrict__ shift,
     float* __restrict__ acc, long long rows, int C, int H, int W, int Ho, int Wo, int cv, int rl, int slabs,
-    int rows_per_block) {
+    int rows_per_block, int nrep) {
     int slab = blockIdx.x % slabs;
     int chunk = blockIdx.x / slabs;
     int col_lane = threadIdx.x % cv;
@@ -349,7 +363,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(
             a1[k] += dy * (yy - mu[k]);
         }
     }
-    block_col_reduce_atomic(a0, a1, cv, rl, col_lane, row_lane, c_base, C, acc);
+    block_col_reduce_atomic(a0, a1, cv, rl, col_lane, row_lane, c_base, C, acc, nrep);
 }
 
 PDT_API int pdt_pool_bn_bwd_reduce_accum(const void* dout, const void* idx, const void* y, const float* mean,
@@ -362,18 +376,18 @@ PDT_API int pdt_pool_bn_bwd_reduce_accum(const void* dout, const void* idx, cons
     ColGeom gm = col_geom(rows, C);
     hipLaunchKernelGGL(pool_bn_bwd_reduce_kernel, dim3(gm.slabs * gm.row_chunks), dim3(256), 0, s, (const bf16*)dout,
                        (const unsigned char*)idx, (const bf16*)y, mean, scale, shift, acc, rows, C, H, W, Ho, Wo, gm.cv,
-                       gm.rl, gm.slabs, gm.rows_per_block);
+                       gm.rl, gm.slabs, gm.rows_per_block, pdt_nrep());
     return pdt_launch_status();
 }
 
 // replicas -> sums [sum(dy), sum(dy*xhat)] ; dbeta += sums[0], dgamma += sums[1] ; zero replicas
 __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(float* __restrict__ acc, const float* __restrict__ invstd,
                                                            float* __restrict__ sums, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int C) {
+                                                           float* __restrict__ dbeta, int C, int nrep) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float s0 = acc_take(acc + c, (size_t)2 * C);
-    float s1 = acc_take(acc + C + c, (size_t)2 * C);
+    float s0 = acc_take(acc + c, (size_t)2 * C, nrep);
+    float s1 = acc_take(acc + C + c, (size_t)2 * C, nrep);
     s1 *= invstd[c];
     sums[c] = s0;
     sums[C + c] = s1;
@@ -385,12 +399,12 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(float* __restrict__ ac
 __global__ __launch_bounds__(1024) void bn_bwd_sums_fused_kernel(const CarDev car, float* __restrict__ acc,
                                                                   const float* __restrict__ invstd,
                                                                   float* __restrict__ sums, float* __restrict__ dgamma,
-                                                                  float* __restrict__ dbeta, int C) {
+                                                                  float* __restrict__ dbeta, int C, int nrep) {
     __shared__ float vals[CAR_MAX_FLOATS];
     __shared__ unsigned ctl[2];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float s0 = acc_take(acc + c, (size_t)2 * C);
-        float s1 = acc_take(acc + C + c, (size_t)2 * C);
+        float s0 = acc_take(acc + c, (size_t)2 * C, nrep);
+        float s1 = acc_take(acc + C + c, (size_t)2 * C, nrep);
         s1 *= invstd[c];
         vals[c] = s0;
         vals[C + c] = s1;
@@ -408,13 +422,14 @@ PDT_API int pdt_bn_bwd_sums_fused(void* car, float* acc, const float* invstd, fl
     if (C < 1 || !car_ready(h, 2 * C)) return -3;
     int threads = C >= 1024 ? 1024 : (C >= 256 ? C : 256);
     hipLaunchKernelGGL(bn_bwd_sums_fused_kernel, dim3(1), dim3(threads), 0, s, h->dev, acc, invstd, sums, dgamma, dbeta,
-                       C);
+                       C, pdt_nrep());
     return pdt_launch_status();
 }
 
 PDT_API int pdt_bn_bwd_sums(float* acc, const float* invstd, float* sums, float* dgamma, float* dbeta, int C,
                             hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, acc, invstd, sums, dgamma, dbeta, C);
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, acc, invstd, sums, dgamma, dbeta, C,
+                       pdt_nrep());
     return pdt_launch_status();
 }
 
@@ -427,8 +442,9 @@ PDT_API int pdt_bn_bwd_sums(float* acc, const float* invstd, float* sums, float*
 #define CE_REG 32   // up to 2048 classes
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const bf16* __restrict__ logits,
                                                           const long long* __restrict__ labels,
-                                                          bf16* __restrict__ dlogits, float* __restrict__ loss, int B,
-                                                          int N, int ld_in, int ld_out, float gscale) {
+                                                          bf16* __restrict__ dlogits, float* __restrict__ loss,
+                                                          float* __restrict__ row_loss, int B, int N, int ld_in,
+                                                          int ld_out, float gscale) {
     int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
     int row = blockIdx.x * 4 + wave;
     if (row >= B) return;
@@ -467,18 +483,40 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const bf16* __restrict_
     if (lane == 0) {
         float lab_logit = (lab >= 0 && lab < N) ? bf2f(src[lab]) : mx;
         float li = logf(se) + mx - lab_logit;
-        atomicAdd(loss, li / (float)B);
+        if (row_loss) row_loss[row] = li;
+        else atomicAdd(loss, li / (float)B);
     }
 }
 
-PDT_API int pdt_softmax_ce(const void* logits, const void* labels, void* dlogits, float* loss, int B, int N,
-                           int ld_in, int ld_out, float gscale, hipStream_t s) {
+// Deterministic loss: sum of the per-row losses in a fixed tree order, one workgroup.
+__global__ __launch_bounds__(256) void ordered_mean_kernel(const float* __restrict__ v, float* __restrict__ out, int n) {
+    __shared__ float red[256];
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0] / (float)n;
+}
+
+// row_loss: [B] scratch of the deterministic variant (the loss is then an ordered sum instead of B float atomics), or NULL
+PDT_API int pdt_softmax_ce(const void* logits, const void* labels, void* dlogits, float* loss, float* row_loss, int B,
+                           int N, int ld_in, int ld_out, float gscale, hipStream_t s) {
     if (N > 64 * CE_REG || ld_out > 64 * CE_REG) return -1;
+    if (row_loss) {
+        hipLaunchKernelGGL(softmax_ce_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, (const bf16*)logits,
+                           (const long long*)labels, (bf16*)dlogits, loss, row_loss, B, N, ld_in, ld_out, gscale);
+        hipLaunchKernelGGL(ordered_mean_kernel, dim3(1), dim3(256), 0, s, row_loss, loss, B);
+        return pdt_launch_status();
+    }
     // zeroed by a kernel, not a memset: inside a captured graph a memset node was seen to run
     // out of order with the kernel that accumulates into the same word
     hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, s, loss, 1);
     hipLaunchKernelGGL(softmax_ce_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, (const bf16*)logits,
-                       (const long long*)labels, (bf16*)dlogits, loss, B, N, ld_in, ld_out, gscale);
+                       (const long long*)labels, (bf16*)dlogits, loss, nullptr, B, N, ld_in, ld_out, gscale);
     return pdt_launch_status();
 }
 
@@ -534,20 +572,23 @@ PDT_API int pdt_ce_metrics(const void* logits, const void* labels, float* out, i
 // (120 us for 512 rows).
 #define COLSUM_ROWS 32
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, float* __restrict__ out, int rows,
-                                                      int N, int ld) {
+                                                      int N, int ld, int rows_per_block) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= N) return;
-    int r0 = blockIdx.y * COLSUM_ROWS;
-    int r1 = r0 + COLSUM_ROWS < rows ? r0 + COLSUM_ROWS : rows;
+    int r0 = blockIdx.y * rows_per_block;
+    int r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float s = 0.0f;
 #pragma unroll 8
     for (int r = r0; r < r1; ++r) s += bf2f(x[(size_t)r * ld + c]);
-    atomicAdd(out + c, s);
+    if (gridDim.y == 1) out[c] += s;          // single writer: plain, ordered
+    else atomicAdd(out + c, s);
 }
 
 PDT_API int pdt_colsum_add(const void* x, float* out, int rows, int N, int ld, hipStream_t s) {
     if (rows <= 0 || N <= 0) return 0;
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256), cdiv(rows, COLSUM_ROWS)), dim3(256), 0, s, (const bf16*)x, out,
-                       rows, N, ld);
+    // deterministic mode: one row chunk, i.e. one thread walks a whole column (slow, ordered)
+    int rpb = g_pdt_deterministic ? rows : COLSUM_ROWS;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256), cdiv(rows, rpb)), dim3(256), 0, s, (const bf16*)x, out,
+                       rows, N, ld, rpb);
     return pdt_launch_status();
 }

@@ -59,7 +59,7 @@ _sig("pdt_bn_finalize", _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, 
 _sig("pdt_bn_eval_affine", _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp)
 _sig("pdt_bn_bwd_reduce_accum", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp)
 _sig("pdt_bn_bwd_sums", _vp, _vp, _vp, _vp, _vp, _i, _vp)
-_sig("pdt_softmax_ce", _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp)
+_sig("pdt_softmax_ce", _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp)
 _sig("pdt_ce_metrics", _vp, _vp, _vp, _i, _i, _i, _vp)
 _sig("pdt_colsum_add", _vp, _vp, _i, _i, _i, _vp)
 _sig("pdt_bn_finalize_fused", _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _vp)
@@ -76,8 +76,11 @@ _sig("pdt_conv_igemm", _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _ll, _i, 
      _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp)
 _sig("pdt_conv_igemm_bstats", _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i,
      _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp)
-_sig("pdt_conv_gemm1x1", _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp)
-_sig("pdt_conv_wgrad", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp)
+_sig("pdt_conv_dma", _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+     _i, _i, _i, _vp, _vp, _vp, _i, _vp)
+_sig("pdt_conv_wgrad", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _ll, _vp)
+_sig("pdt_set_deterministic", _i)
+_sig("pdt_accumulator_rows")
 
 
 _sig("pdt_transpose_w_batched", _vp, _vp, _vp, _i, _i, _vp)
@@ -178,6 +181,44 @@ def _f32c(t: torch.Tensor, what: str) -> torch.Tensor:
 # --------------------------------------------------------------------------- small caches
 _acc_cache: Dict[Tuple[int, int, str], torch.Tensor] = {}
 
+# ---- deterministic mode ---------------------------------------------------------------------
+# Float atomics make the low bits of BatchNorm statistics, weight gradients and the loss depend on the
+# order in which workgroups finish.  ``set_deterministic(True)`` switches the library to single-writer
+# accumulator rows folded in index order, weight gradients through per-slice slabs added in slice order,
+# and ordered sums for the loss and the classifier bias: two runs on the same inputs then give the same
+# bits (``runtime.deterministic``), a few percent slower.
+_deterministic = False
+_wgrad_ws: Dict[Tuple[int, int], torch.Tensor] = {}
+WGRAD_WORKSPACE_BYTES = 128 << 20
+
+
+def set_deterministic(on: bool) -> None:
+    global _deterministic, NREP
+    torch.cuda.synchronize()
+    _check(_real.pdt_set_deterministic(int(bool(on))), "pdt_set_deterministic")
+    _deterministic = bool(on)
+    NREP = int(_real.pdt_accumulator_rows())
+    _acc_cache.clear()         # the accumulators are sized by the number of replica rows
+    if not on:
+        _wgrad_ws.clear()
+
+
+def is_deterministic() -> bool:
+    return _deterministic
+
+
+def _wgrad_workspace(device: torch.device, stream: int):
+    """Slab workspace of the deterministic weight-gradient kernel: one per stream, because launches on
+    different streams may run at the same time."""
+    if not _deterministic:
+        return None, 0
+    key = (device.index or 0, stream)
+    ws = _wgrad_ws.get(key)
+    if ws is None:
+        ws = torch.empty(WGRAD_WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+        _wgrad_ws[key] = ws
+    return ws.data_ptr(), ws.numel() * 4
+
 
 def _accumulator(device: torch.device, C: int, kind: str) -> torch.Tensor:
     """Persistent zero-initialised ``[NREP, 2, C]`` accumulator (kernels re-zero it after use)."""
@@ -274,6 +315,16 @@ def _igemm(inp, wgt, out, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0
                    stat_acc=stat_acc, stat_shift=stat_shift, tile=tile, bstat=sub, mask_bits=mask_bits,
                    addend_half=addend_half)
         return
+    if (_USE_CONV_DMA and tile <= 0 and bias is None and ldo == N and N % 64 == 0 and Ci % 64 == 0 and taps.T >= 1
+            and pix_stride % 8 == 0 and (mask is None or mask_bits) and (_DMA_TAPS or taps.T == 1)
+            and inp.numel() * 2 < 0x7fff0000 and N * wrow * 2 < 0x7fff0000):
+        acc, by, bmean, bscale, bshift = bstat if bstat is not None else (stat_acc, None, None, None, None)
+        rc = _lib.pdt_conv_dma(_p(inp), _p(wgt), _p(out), _p(addend), int(addend_half), _p(mask), _p(acc), _p(stat_shift),
+                               _p(by), _p(bmean), _p(bscale), _p(bshift), M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS,
+                               oy0, ox0, N, wrow, taps.T, taps.offy, taps.offx, taps.widx, -tile or _DMA_TILE, _stream())
+        _check(rc, "pdt_conv_dma")
+        return
+    tile = max(tile, 0)
     if bstat is not None:        # (acc, y, mean, scale-or-None, shift-or-None): BN-backward sums of the consumer
         acc, by, bmean, bscale, bshift = bstat
         rc = _lib.pdt_conv_igemm_bstats(_p(inp), _p(wgt), _p(out), _p(addend), int(addend_half), _p(mask), int(mask_bits), _p(acc), _p(by), _p(bmean),
@@ -298,28 +349,21 @@ def _wgrad(dy, inp, dw, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow, tap
             _wgrad(dy[b0:b1], inp[b0:b1], dw, (M // B) * (b1 - b0), Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow,
                    taps, tile=tile, target_blocks=target_blocks, atomic_budget_mb=atomic_budget_mb)
         return
+    stream = _stream()
+    ws, ws_bytes = _wgrad_workspace(dw.device, stream)
     rc = _lib.pdt_conv_wgrad(_p(dy), _p(inp), _p(dw), M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow, taps.T,
-                             taps.offy, taps.offx, taps.widx, tile, target_blocks, atomic_budget_mb, _stream())
+                             taps.offy, taps.offx, taps.widx, tile, target_blocks, atomic_budget_mb, ws, ws_bytes,
+                             stream)
     _check(rc, "pdt_conv_wgrad")
 
 
-# 1x1 convolutions go to the streaming LDS-DMA GEMM (csrc/conv_gemm1x1.hip) when its shape rules hold;
-# PDT_GEMM1X1=0 keeps every convolution on the general implicit-GEMM kernel (A/B measurements).
-_USE_GEMM1X1 = os.environ.get("PDT_GEMM1X1", "1") == "1"
-_G1_TILE = int(os.environ.get("PDT_G1_TILE", "0"))          # measurement override of the 1x1 kernel's tile choice
-
-
-def _gemm1x1_ok(a: torch.Tensor, K: int, N: int, out: torch.Tensor) -> bool:
-    return _USE_GEMM1X1 and K % 64 == 0 and N % 64 == 0 and a.numel() * 2 < 0x7fff0000 and N * K * 2 < 0x7fff0000
-
-
-def _gemm1x1(a, w, out, M, N, K, a_stride, Hg, Wg, IS, Hi, Wi, addend=None, addend_half=False, mask_bits=None,
-             stat_acc=None, stat_shift=None, bstat=None, tile: int = 0) -> None:
-    acc, by, bmean, bscale, bshift = bstat if bstat is not None else (stat_acc, None, None, None, None)
-    rc = _lib.pdt_conv_gemm1x1(_p(a), _p(w), _p(out), _p(addend), int(addend_half), _p(mask_bits), _p(acc), _p(stat_shift),
-                               _p(by), _p(bmean), _p(bscale), _p(bshift), M, N, K, a_stride, Hg, Wg, IS, Hi, Wi,
-                               tile or _G1_TILE, _stream())
-    _check(rc, "pdt_conv_gemm1x1")
+# Convolutions go to the streaming LDS-DMA kernel (csrc/conv_dma.hip) when its shape rules hold (channel counts in
+# multiples of 64, dense output rows, no bias, ReLU mask in packed form): everything in a ResNet but the stem and the
+# classifier.  PDT_CONV_DMA=0 keeps every convolution on the register-staged implicit-GEMM kernel (A/B measurements);
+# a positive ``tile`` argument selects a tile of that kernel, a negative one a tile of the DMA kernel.
+_USE_CONV_DMA = os.environ.get("PDT_CONV_DMA", "1") == "1"
+_DMA_TILE = int(os.environ.get("PDT_DMA_TILE", "0"))          # measurement override of the DMA kernel's tile choice
+_DMA_TAPS = os.environ.get("PDT_CONV_DMA_TAPS", "1") == "1"   # 0: only single-tap (1x1) launches use the DMA kernel
 
 
 class PendingStats:
@@ -485,13 +529,10 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pa
     y = _out_like(out, (B, Ho, Wo, Co), x.device, "conv_fprop")
     M = B * Ho * Wo
     acc = _accumulator(x.device, Co, acc_slot) if stat_shift is not None else None
-    if R == 1 and S == 1 and pad == 0 and tile <= 0 and _gemm1x1_ok(x, Ci, Co, y):
-        _gemm1x1(x, w, y, M, Co, Ci, Ci, Ho, Wo, stride, Hi, Wi, stat_acc=acc, stat_shift=stat_shift, tile=-tile)
-    else:
-        if tile == 0 and R == S and Hi == Wi:
-            tile = _tile_hint("fprop", B, Ci, Co, R, stride, Hi)
-        _igemm(x, w, y, M, Hi, Wi, Ci, Ci, Ho, Wo, stride, Ho, Wo, 1, 0, 0, Co, Co, R * S * Ci, _fprop_taps(R, S, pad),
-               stat_acc=acc, stat_shift=stat_shift, tile=max(tile, 0))
+    if tile == 0 and R == S and Hi == Wi and not _USE_CONV_DMA:
+        tile = _tile_hint("fprop", B, Ci, Co, R, stride, Hi)
+    _igemm(x, w, y, M, Hi, Wi, Ci, Ci, Ho, Wo, stride, Ho, Wo, 1, 0, 0, Co, Co, R * S * Ci, _fprop_taps(R, S, pad),
+           stat_acc=acc, stat_shift=stat_shift, tile=tile)
     if acc is None:
         return y, None
     return y, (PendingStats(acc, Co, M) if defer_stats else _moments_from_acc(acc, Co, M))
@@ -523,7 +564,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
         mask_src = relu_bits
     elif relu_mask is not None:
         mask_src = _bf16c(relu_mask, "conv_dgrad relu_mask")
-    if tile == 0 and R == S and Hi == Wi:
+    if tile == 0 and R == S and Hi == Wi and not _USE_CONV_DMA:
         tile = _tile_hint("dgrad", B, Ci, Co, R, stride, Hi)
     bstat = None
     if bwd_stats is not None:
@@ -536,12 +577,6 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
                  bshift if recompute else None)
     if bstat is not None and mask_src is not None and not bits:
         raise ValueError("conv_dgrad: with bwd_stats the ReLU mask must be given in packed form (relu_bits)")
-    if R == 1 and S == 1 and pad == 0 and stride == 1 and tile <= 0 and (mask_src is None or bits) \
-            and _gemm1x1_ok(dy, Co, Ci, dx):
-        _gemm1x1(dy, wt, dx, B * Hi * Wi, Ci, Co, Co, Hi, Wi, 1, Hi, Wi, addend=addend, addend_half=addend_half,
-                 mask_bits=mask_src, bstat=bstat, tile=-tile)
-        return dx
-    tile = max(tile, 0)          # (negative values select tiles of the 1x1 kernel only)
     if stride == 1:
         _igemm(dy, wt, dx, B * Hi * Wi, Ho, Wo, Co, Co, Hi, Wi, 1, Hi, Wi, 1, 0, 0, Ci, Ci, R * S * Co,
                _dgrad_taps(R, S, pad, 1, 0, 0), addend=addend, mask=mask_src, tile=tile, bstat=bstat, mask_bits=bits,
@@ -866,8 +901,9 @@ def softmax_ce(logits, labels, grad_scale: float = 1.0):
     dlog = torch.empty(B, ld_out, dtype=torch.bfloat16, device=logits.device)
     loss = torch.empty(1, dtype=torch.float32, device=logits.device)
     labels = labels if labels.dtype == torch.int64 else labels.long()
-    rc = _lib.pdt_softmax_ce(_p(logits), _p(labels.contiguous()), _p(dlog), _p(loss), B, N, logits.stride(0), ld_out,
-                             grad_scale, _stream())
+    row_loss = torch.empty(B, dtype=torch.float32, device=logits.device) if _deterministic else None
+    rc = _lib.pdt_softmax_ce(_p(logits), _p(labels.contiguous()), _p(dlog), _p(loss), _p(row_loss), B, N,
+                             logits.stride(0), ld_out, grad_scale, _stream())
     _check(rc, "pdt_softmax_ce")
     return loss[0], dlog[:, :N]
 

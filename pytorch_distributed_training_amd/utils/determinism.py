@@ -16,10 +16,11 @@ import torch
 def make_deterministic(seed: int, strict: bool = False) -> None:
     """Seed python, numpy and torch (CPU and every visible GPU) RNGs.
 
-    ``strict=True`` additionally asks torch for deterministic algorithms; the hand-written
-    weight-gradient kernels accumulate with float atomics, so bitwise reproducibility of
-    a GPU run is not promised either way (upstream is not bit-deterministic either: it
-    enables cudnn autotuning right after seeding, ``train_distributed.py:54``).
+    ``strict=True`` (``runtime.deterministic``) additionally asks torch for deterministic
+    algorithms; the same config key makes the native engine switch its HIP kernels to ordered
+    reductions (``ops.hip.set_deterministic``), so two GPU runs with one seed end with the same
+    parameter bits.  Upstream is not bit-deterministic: it enables cudnn autotuning right after
+    seeding (``train_distributed.py:54``).
     """
     seed = int(seed)
     os.environ.setdefault("PYTHONHASHSEED", str(seed))

@@ -47,7 +47,7 @@ MULTI_TILE = [
     (64, 14, 256, 1024, 1, 1, 0, 0),    # automatic choice
     (64, 14, 1024, 256, 1, 1, 0, 5),    # 64x128 tile, 16 K-steps
     (64, 28, 128, 512, 1, 1, 0, 3),     # 64x64 tile: 6272 tiles
-    # the streaming 1x1 kernel (negative tile = its own tile numbering): 128x128 and 128x64 tiles, one to
+    # the streaming DMA kernel (negative tile = its own tile numbering): 128x128 and 128x64 tiles, one to
     # sixteen K steps per tile, several tiles per workgroup, a channel-tile change inside a workgroup's sequence
     (16, 56, 64, 256, 1, 1, 0, -1), (16, 56, 64, 384, 1, 1, 0, -1), (64, 28, 128, 512, 1, 1, 0, -1),
     (16, 56, 256, 64, 1, 1, 0, -2), (64, 14, 1024, 256, 1, 1, 0, -1), (64, 14, 1024, 256, 1, 1, 0, -2),
@@ -55,6 +55,11 @@ MULTI_TILE = [
     # the same kernel with K slices of 64: two-stage (128x128) and three-stage (128x64) rings
     (16, 56, 64, 256, 1, 1, 0, -3), (64, 28, 128, 512, 1, 1, 0, -3), (16, 56, 256, 64, 1, 1, 0, -4),
     (64, 14, 1024, 256, 1, 1, 0, -3), (33, 14, 512, 192, 1, 1, 0, -4), (3, 7, 64, 64, 1, 1, 0, -2),
+    # ... and with tap tables: 3x3 with zero padding (taps outside the image must read zeros through the DMA), stride 2
+    # (forward gather; data gradient in four output-parity launches), 14x14 and 7x7 images whose rows wrap inside a tile
+    (64, 28, 128, 128, 3, 1, 1, -3), (64, 56, 64, 64, 3, 1, 1, -4), (16, 56, 256, 128, 3, 2, 1, -3),
+    (64, 14, 256, 256, 3, 1, 1, -1), (33, 7, 512, 512, 3, 1, 1, -3), (16, 28, 256, 256, 3, 2, 1, -2),
+    (5, 9, 64, 192, 3, 1, 1, -4), (2, 15, 128, 64, 3, 2, 1, -3),
 ]
 
 
