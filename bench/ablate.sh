@@ -19,3 +19,7 @@ run "full step" PDT_ABLATE=
 run "weight gradients dropped (critical stream alone)" PDT_ABLATE=wgrad
 run "weight gradients on the critical stream (serial)" PDT_WGRAD_STREAM=0
 run "optimizer after backward (whole model, one kernel)" PDT_OPT_IN_BACKWARD=0
+run "every other weight gradient dropped" PDT_ABLATE=wgrad_half
+run "BatchNorm-backward elementwise passes dropped" PDT_ABLATE=elemt
+run "BatchNorm-forward elementwise passes (no residual) dropped" PDT_ABLATE=apply
+run "full step again" PDT_ABLATE=

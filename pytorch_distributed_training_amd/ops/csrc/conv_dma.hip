@@ -321,17 +321,23 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
             stat_n0 = n0;
             load_consts(nb);
         }
-        // epilogue operands of all MI row groups first, so they are all in flight together
-        size_t oidx[MI];
-        bool live[MI];
-        u32x4 yv[BSTAT ? MI : 1][2], av[MI][2];
-        unsigned mb[MI];
+        // Epilogue operands of EG row groups first, so they are all in flight together: all MI of them, except with
+        // the backward-sums epilogue on a 64-row wave tile, where four groups of loads on top of the 80 registers of
+        // sums and per-channel constants would not fit 256 VGPRs -- two passes of two groups there.
+        constexpr int EG = (BSTAT && MI > 2) ? 2 : MI;
         const bool has_addend = p.addend != nullptr, has_mask = p.mask_bits != nullptr;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        for (int i0 = 0; i0 < MI; i0 += EG) {
+        size_t oidx[EG];
+        bool live[EG];
+        u32x4 yv[BSTAT ? EG : 1][2], av[EG][2];
+        unsigned mb[EG];
+#pragma unroll
+        for (int e = 0; e < EG; ++e) {
+            const int i = i0 + e;
             const int mi = m0 + wm * WTM + i * 16 + frow;
-            live[i] = mi < p.M;
-            const int m = live[i] ? mi : p.M - 1;
+            live[e] = mi < p.M;
+            const int m = live[e] ? mi : p.M - 1;
             unsigned yo = 0, xo = 0, bimg = 0;
             size_t orow = (size_t)m;
             if (!p.simple_out || p.addend_half) {
@@ -343,11 +349,11 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
                 if (!p.simple_out) orow = ((size_t)bimg * p.Ho + yo) * p.Wo + xo;
             }
             const size_t o = orow * p.N + nb;
-            oidx[i] = o;
+            oidx[e] = o;
             if (BSTAT) {
                 const u32x4* yp = reinterpret_cast<const u32x4*>(p.bstat_y + o);
-                yv[i][0] = yp[0];
-                yv[i][1] = yp[1];
+                yv[e][0] = yp[0];
+                yv[e][1] = yp[1];
             }
             if (has_addend) {
                 long long ai = (long long)o;
@@ -356,17 +362,18 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
                                           : (long long)((((size_t)bimg * (p.Ho >> 1) + (yo >> 1)) * (p.Wo >> 1) + (xo >> 1)) * p.N + nb);
                 if (ai >= 0) {
                     const u32x4* ap = reinterpret_cast<const u32x4*>(p.addend + ai);
-                    av[i][0] = __builtin_nontemporal_load(ap);        // last use of the incoming gradient
-                    av[i][1] = __builtin_nontemporal_load(ap + 1);
+                    av[e][0] = __builtin_nontemporal_load(ap);        // last use of the incoming gradient
+                    av[e][1] = __builtin_nontemporal_load(ap + 1);
                 } else {
-                    av[i][0] = u32x4{0u, 0u, 0u, 0u};
-                    av[i][1] = u32x4{0u, 0u, 0u, 0u};
+                    av[e][0] = u32x4{0u, 0u, 0u, 0u};
+                    av[e][1] = u32x4{0u, 0u, 0u, 0u};
                 }
             }
-            if (has_mask) mb[i] = *reinterpret_cast<const unsigned short*>(p.mask_bits + (o >> 3));
+            if (has_mask) mb[e] = *reinterpret_cast<const unsigned short*>(p.mask_bits + (o >> 3));
         }
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        for (int e = 0; e < EG; ++e) {
+            const int i = i0 + e;
             // bf16 pairs: register j of lane group fq holds channels j*16 + fq*4 + {0,1} / {2,3}
             unsigned lo[4], hi[4];
 #pragma unroll
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
-                        const unsigned a = av[i][h][d];
+                        const unsigned a = av[e][h][d];
                         const int k = h * 8 + d * 2;
                         val[k] = bf2f(f2bf(val[k] + bf_lo(a)));
                         val[k + 1] = bf2f(f2bf(val[k + 1] + bf_hi(a)));
@@ -399,16 +406,16 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
             }
             if (has_mask) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) val[k] = ((mb[i] >> k) & 1u) ? val[k] : 0.0f;
+                for (int k = 0; k < 16; ++k) val[k] = ((mb[e] >> k) & 1u) ? val[k] : 0.0f;
             }
-            if (live[i]) {
+            if (live[e]) {
                 u32x4 o0, o1;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     o0[d] = pack2(val[d * 2], val[d * 2 + 1]);
                     o1[d] = pack2(val[8 + d * 2], val[8 + d * 2 + 1]);
                 }
-                u32x4* op = reinterpret_cast<u32x4*>(p.out + oidx[i]);
+                u32x4* op = reinterpret_cast<u32x4*>(p.out + oidx[e]);
                 __builtin_nontemporal_store(o0, op);
                 __builtin_nontemporal_store(o1, op + 1);
                 if (BSTAT) {
@@ -416,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
                     for (int h = 0; h < 2; ++h)
 #pragma unroll
                         for (int d = 0; d < 4; ++d) {
-                            const unsigned yy2 = yv[i][h][d];
+                            const unsigned yy2 = yv[e][h][d];
                             const int k = h * 8 + d * 2;
                             float y0 = bf_lo(yy2), y1 = bf_hi(yy2);
                             float d0 = val[k], d1 = val[k + 1];
@@ -438,6 +445,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
                     }
                 }
             }
+        }
         }
         if (!more) break;
         v = vn;
@@ -510,14 +518,12 @@ PDT_API int pdt_conv_dma(const void* in, const void* wgt, void* out, const void*
     for (int i = T; i < DMA_MAX_TAPS; ++i) p.taps[i] = 0;
     const bool bs = bstat_y != nullptr;
     // Tiles: 3 = 128 x 128 (2 x 2 waves, K slices of 64, ring of 2), 4 = 128 x 64 (4 x 1 waves, ring of 3).  Tiles 1 / 2
-    // named ring-of-4 pipelines on K slices of 32, which measured slower everywhere; they now select 3 / 4.  A
-    // 128-wide tile is not built with the backward-statistics epilogue (its 16 extra per-lane sums push the kernel
-    // past 256 VGPRs into scratch; those launches are short-K and bandwidth bound, the narrow tile costs nothing).
+    // named ring-of-4 pipelines on K slices of 32, which measured slower everywhere; they now select 3 / 4.
     if (tile == 1 || tile == 2) tile += 2;
     if (tile == 0) tile = (N % 128 == 0) ? 3 : 4;
-    if (tile == 3 && (N % 128 != 0 || bs)) tile = 4;
+    if (tile == 3 && N % 128 != 0) tile = 4;
     switch (tile) {
-        case 3: return g1_launch<128, 2, 2, 64, 2, false>(p, s);
+        case 3: return bs ? g1_launch<128, 2, 2, 64, 2, true>(p, s) : g1_launch<128, 2, 2, 64, 2, false>(p, s);
         case 4: return bs ? g1_launch<64, 4, 1, 64, 3, true>(p, s) : g1_launch<64, 4, 1, 64, 3, false>(p, s);
         default: return -6;
     }

@@ -41,6 +41,7 @@ struct WgradParams {
     int N, ldy, wrow, T;
     int splitk;
     long long rows_per_split;
+    int step_b, step_y, step_x;        // BKP GEMM rows as (images, grid rows, grid columns): see row_advance
     // one 32-bit word per tap: offy (int8) | offx (int8) << 8 | widx (uint16) << 16.  Sub-dword
     // entries would be fetched with VECTOR loads (no scalar byte loads on gfx9), whose waits
     // drain the tile prefetches; a dword indexed by a wave-uniform tap is one s_load_dword.
@@ -63,18 +64,47 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char* base0, const
     return u.v;
 }
 
-template <int BMO, int BNC, int WM, int WN>
+// Position of a GEMM row (an output pixel) as (image, y, x) on the Hg x Wg grid, advanced by one K step (BKP rows) at a
+// time with the launch-constant increment (step_b, step_y, step_x): two compares and a handful of adds per step instead
+// of two integer divisions per staged row (which made the main loop VALU-bound: ~200 vector instructions against 32 MFMAs).
+struct RowPos {
+    int b, y, x;
+};
+
+__device__ __forceinline__ RowPos row_pos(unsigned m, int HgWg, int Wg) {
+    RowPos r;
+    r.b = (int)(m / (unsigned)HgWg);
+    int rem = (int)(m - (unsigned)r.b * (unsigned)HgWg);
+    r.y = (int)((unsigned)rem / (unsigned)Wg);
+    r.x = rem - r.y * Wg;
+    return r;
+}
+
+__device__ __forceinline__ void row_advance(RowPos& r, const WgradParams& p) {
+    r.x += p.step_x;
+    int cx = r.x >= p.Wg;
+    r.x -= cx ? p.Wg : 0;
+    r.y += p.step_y + cx;
+    int cy = r.y >= p.Hg;
+    r.y -= cy ? p.Hg : 0;
+    r.b += p.step_b + cy;
+}
+
+// LINEAR: the gathered operand is the input tensor itself (1x1 filter, stride 1, no padding): GEMM row m reads input
+// pixel m, so both operands advance by a constant byte stride per K step and the slice end is enforced by the buffer
+// descriptors' sizes -- no per-row index arithmetic at all.
+template <int BMO, int BNC, int WM, int WN, bool LINEAR>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     constexpr int RSA = (BMO + 16) * 2;       // LDS row stride (bytes), dY tile
     constexpr int RSB = (BNC + 16) * 2;       // LDS row stride (bytes), X tile
     constexpr int A_BYTES = BKP * RSA, B_BYTES = BKP * RSB;
     constexpr int AV = BMO / 8, BV = BNC / 8; // 16-byte vectors per tile row
     constexpr int A_RPP = 256 / AV, B_RPP = 256 / BV;
-    constexpr int A_IT = (BKP + A_RPP - 1) / A_RPP, B_IT = (BKP + B_RPP - 1) / B_RPP;
+    constexpr int A_IT = BKP / A_RPP, B_IT = BKP / B_RPP;
     constexpr int WTM = BMO / WM, WTN = BNC / WN;
     constexpr int MI = WTM / 16, NI = WTN / 16;
-    static_assert(A_RPP <= BKP ? BKP % A_RPP == 0 : true, "");
-    static_assert(B_RPP <= BKP ? BKP % B_RPP == 0 : true, "");
+    static_assert(A_RPP <= BKP && BKP % A_RPP == 0, "every thread stages whole rows of the dY tile");
+    static_assert(B_RPP <= BKP && BKP % B_RPP == 0, "every thread stages whole rows of the X tile");
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
 
@@ -101,59 +131,73 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     int oy, ox, wi_tap;
     unpack_tap(p.taps[__builtin_amdgcn_readfirstlane(tap)], oy, ox, wi_tap);
 
-    const long long r_begin = (long long)split * p.rows_per_split;
-    long long r_end = r_begin + p.rows_per_split;
-    if (r_end > p.M) r_end = p.M;
+    // M < 2^31 (checked by the launcher): 32-bit row arithmetic
+    const unsigned r_begin = (unsigned)((long long)split * p.rows_per_split);
+    unsigned r_end = r_begin + (unsigned)p.rows_per_split;
+    if (r_end > (unsigned)p.M) r_end = (unsigned)p.M;
     const int nk = r_begin < r_end ? (int)((r_end - r_begin + BKP - 1) / BKP) : 0;
+    if (nk == 0) return;
 
     const int a_cv = tid % AV, a_row = tid / AV;
     const int b_cv = tid % BV, b_row = tid / BV;
     const bool a_col_ok = co0 + a_cv * 8 < p.N;          // N is checked at 8-granularity (ldy padded)
     const bool b_col_ok = ci0 + b_cv * 8 < p.Ci;
-    const int HgWg = p.Hg * p.Wg;
 
-    const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(p.dy, p.dy_bytes);
-    const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(p.in, p.in_bytes);
+    // The dY descriptor ends at this slice's last row: rows past the slice read zeros through the range check.
+    const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(p.dy, (unsigned)((unsigned long long)r_end * (unsigned)p.ldy * 2u));
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        make_rsrc(p.in, LINEAR ? (unsigned)((unsigned long long)r_end * (unsigned)p.pix_stride * 2u) : p.in_bytes);
     bf16x8 a_reg[A_IT], b_reg[B_IT];
-    // branch-free staging loads: lanes outside the slice / tile / image read zeros through the
-    // buffer descriptor's range check
-    auto load_tiles = [&](long long r0) {
+    unsigned a_off[A_IT], b_off[B_IT];
+    RowPos pos[B_IT];
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) {
+        unsigned m = r_begin + a_row + j * A_RPP;
+        a_off[j] = a_col_ok ? (m * (unsigned)p.ldy + co0 + a_cv * 8) * 2u : PDT_OOB_OFFSET;
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+        unsigned m = r_begin + b_row + j * B_RPP;
+        if (LINEAR) b_off[j] = b_col_ok ? (m * (unsigned)p.pix_stride + ci0 + b_cv * 8) * 2u : PDT_OOB_OFFSET;
+        else pos[j] = row_pos(m, p.Hg * p.Wg, p.Wg);
+    }
+    const unsigned a_step = a_col_ok ? (unsigned)(BKP * p.ldy * 2) : 0u;
+    const unsigned b_step = b_col_ok ? (unsigned)(BKP * p.pix_stride * 2) : 0u;
+    const unsigned b_col = (unsigned)(ci0 + b_cv * 8);
+    unsigned m_b = r_begin + b_row;                        // GEMM row of this thread's first X row in the coming K step
+
+    // branch-free staging loads: rows outside the slice / tile / image read zeros through the range check
+    auto load_tiles = [&]() {
 #pragma unroll
         for (int j = 0; j < A_IT; ++j) {
-            int row = a_row + j * A_RPP;
-            long long m = r0 + row;
-            bool ok = row < BKP && m < r_end && a_col_ok;
-            unsigned off = (unsigned)((unsigned)m * (unsigned)p.ldy + co0 + a_cv * 8) * 2u;
-            a_reg[j] = buf_ld_bf16x8(dy_rsrc, ok ? off : PDT_OOB_OFFSET);
+            a_reg[j] = buf_ld_bf16x8(dy_rsrc, a_off[j]);
+            a_off[j] += a_step;
         }
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) {
-            int row = b_row + j * B_RPP;
-            long long m = r0 + row;
-            unsigned mu = m < r_end ? (unsigned)m : 0u;         // M < 2^31 (checked by the launcher)
-            int b = (int)(mu / (unsigned)HgWg);
-            int rem = (int)(mu - (unsigned)b * (unsigned)HgWg);
-            int y = (int)((unsigned)rem / (unsigned)p.Wg), x = rem - y * p.Wg;
-            int iy = y * p.IS + oy, ix = x * p.IS + ox;
-            bool ok = row < BKP && m < r_end && b_col_ok && (unsigned)iy < (unsigned)p.Hi &&
-                      (unsigned)ix < (unsigned)p.Wi;
-            unsigned off = (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.pix_stride + ci0 + b_cv * 8) * 2u;
-            b_reg[j] = buf_ld_bf16x8(in_rsrc, ok ? off : PDT_OOB_OFFSET);
+            if (LINEAR) {
+                b_reg[j] = buf_ld_bf16x8(in_rsrc, b_off[j]);
+                b_off[j] += b_step;
+            } else {
+                int iy = pos[j].y * p.IS + oy, ix = pos[j].x * p.IS + ox;
+                bool ok = m_b + j * B_RPP < r_end && b_col_ok && (unsigned)iy < (unsigned)p.Hi &&
+                          (unsigned)ix < (unsigned)p.Wi;
+                unsigned off = (unsigned)(((pos[j].b * p.Hi + iy) * p.Wi + ix) * p.pix_stride + b_col) * 2u;
+                b_reg[j] = buf_ld_bf16x8(in_rsrc, ok ? off : PDT_OOB_OFFSET);
+                row_advance(pos[j], p);
+            }
         }
+        m_b += BKP;
     };
     auto store_tiles = [&](int buf) {
         unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
         unsigned char* Bs = As + A_BYTES;
 #pragma unroll
-        for (int j = 0; j < A_IT; ++j) {
-            int row = a_row + j * A_RPP;
-            if (row < BKP) *reinterpret_cast<bf16x8*>(As + row * RSA + a_cv * 16) = a_reg[j];
-        }
+        for (int j = 0; j < A_IT; ++j)
+            *reinterpret_cast<bf16x8*>(As + (a_row + j * A_RPP) * RSA + a_cv * 16) = a_reg[j];
 #pragma unroll
-        for (int j = 0; j < B_IT; ++j) {
-            int row = b_row + j * B_RPP;
-            if (row < BKP) *reinterpret_cast<bf16x8*>(Bs + row * RSB + b_cv * 16) = b_reg[j];
-        }
+        for (int j = 0; j < B_IT; ++j)
+            *reinterpret_cast<bf16x8*>(Bs + (b_row + j * B_RPP) * RSB + b_cv * 16) = b_reg[j];
     };
 
     f32x4 acc[MI][NI];
@@ -168,43 +212,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     const int trow0 = 4 * g + q4;             // pixel row of read #0 inside a 32-pixel step
     const int tcol = 4 * pp;                  // channel offset inside the 16-channel block
 
-    if (nk > 0) {
-        load_tiles(r_begin);
-        store_tiles(0);
-        __syncthreads();
-        int cur = 0;
-        for (int ks = 0; ks < nk; ++ks) {
-            const bool has_next = ks + 1 < nk;
-            if (has_next) load_tiles(r_begin + (long long)(ks + 1) * BKP);
-            const unsigned char* As = smem + cur * (A_BYTES + B_BYTES);
-            const unsigned char* Bs = As + A_BYTES;
+    load_tiles();
+    store_tiles(0);
+    __syncthreads();
+    int cur = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        const bool has_next = ks + 1 < nk;
+        if (has_next) load_tiles();
+        const unsigned char* As = smem + cur * (A_BYTES + B_BYTES);
+        const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
-            for (int kk = 0; kk < BKP / 32; ++kk) {
-                bf16x8 af[MI], bfr[NI];
-                const int r0 = kk * 32 + trow0, r1 = r0 + 16;
+        for (int kk = 0; kk < BKP / 32; ++kk) {
+            bf16x8 af[MI], bfr[NI];
+            const int r0 = kk * 32 + trow0, r1 = r0 + 16;
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    int col = wm * WTM + i * 16 + tcol;
-                    af[i] = tr_read_pair(As + r0 * RSA + col * 2, As + r1 * RSA + col * 2);
-                }
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    int col = wn * WTN + j * 16 + tcol;
-                    bfr[j] = tr_read_pair(Bs + r0 * RSB + col * 2, Bs + r1 * RSB + col * 2);
-                }
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < MI; ++i) {
+                int col = wm * WTM + i * 16 + tcol;
+                af[i] = tr_read_pair(As + r0 * RSA + col * 2, As + r1 * RSA + col * 2);
             }
-            if (has_next) store_tiles(cur ^ 1);
-            __syncthreads();
-            cur ^= 1;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                int col = wn * WTN + j * 16 + tcol;
+                bfr[j] = tr_read_pair(Bs + r0 * RSB + col * 2, Bs + r1 * RSB + col * 2);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
+        if (has_next) store_tiles(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
     }
 
-    if (nk == 0) return;
     const int frow = lane & 15, fq = lane >> 4;
     const long long wofs = (long long)wi_tap * p.Ci;
 #pragma unroll
@@ -265,9 +306,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(const WgradParams p)
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) unpack_tap(p.taps[grp * TAPS + t], oy[t], ox[t], wi_tap[t]);
 
-    const long long r_begin = (long long)split * p.rows_per_split;
-    long long r_end = r_begin + p.rows_per_split;
-    if (r_end > p.M) r_end = p.M;
+    const unsigned r_begin = (unsigned)((long long)split * p.rows_per_split);
+    unsigned r_end = r_begin + (unsigned)p.rows_per_split;
+    if (r_end > (unsigned)p.M) r_end = (unsigned)p.M;
     const int nk = r_begin < r_end ? (int)((r_end - r_begin + BKP - 1) / BKP) : 0;
     if (nk == 0) return;
 
@@ -275,36 +316,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(const WgradParams p)
     const int b_cv = tid % BV, b_row = tid / BV;
     const bool a_col_ok = co0 + a_cv * 8 < p.N;
     const bool b_col_ok = b_cv * 8 < p.Ci;
-    const int HgWg = p.Hg * p.Wg;
 
-    const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(p.dy, p.dy_bytes);
+    const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(p.dy, (unsigned)((unsigned long long)r_end * (unsigned)p.ldy * 2u));
     const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(p.in, p.in_bytes);
     bf16x8 a_reg[A_IT], b_reg[TAPS][B_IT];
-    auto load_tiles = [&](long long r0) {
+    unsigned a_off[A_IT];
+    RowPos pos[B_IT];
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) {
+        unsigned m = r_begin + a_row + j * A_RPP;
+        a_off[j] = a_col_ok ? (m * (unsigned)p.ldy + co0 + a_cv * 8) * 2u : PDT_OOB_OFFSET;
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) pos[j] = row_pos(r_begin + b_row + j * B_RPP, p.Hg * p.Wg, p.Wg);
+    const unsigned a_step = a_col_ok ? (unsigned)(BKP * p.ldy * 2) : 0u;
+    unsigned m_b = r_begin + b_row;
+    auto load_tiles = [&]() {
 #pragma unroll
         for (int j = 0; j < A_IT; ++j) {
-            int row = a_row + j * A_RPP;
-            long long m = r0 + row;
-            bool ok = m < r_end && a_col_ok;
-            unsigned off = (unsigned)((unsigned)m * (unsigned)p.ldy + co0 + a_cv * 8) * 2u;
-            a_reg[j] = buf_ld_bf16x8(dy_rsrc, ok ? off : PDT_OOB_OFFSET);
+            a_reg[j] = buf_ld_bf16x8(dy_rsrc, a_off[j]);
+            a_off[j] += a_step;
         }
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) {
-            int row = b_row + j * B_RPP;
-            long long m = r0 + row;
-            unsigned mu = m < r_end ? (unsigned)m : 0u;
-            int b = (int)(mu / (unsigned)HgWg);
-            int rem = (int)(mu - (unsigned)b * (unsigned)HgWg);
-            int y = (int)((unsigned)rem / (unsigned)p.Wg), x = rem - y * p.Wg;
+            const bool row_ok = m_b + j * B_RPP < r_end && b_col_ok;
+            const int y0 = pos[j].y * p.IS, x0 = pos[j].x * p.IS;
+            const int base = pos[j].b * p.Hi;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
-                int iy = y * p.IS + oy[t], ix = x * p.IS + ox[t];
-                bool ok = m < r_end && b_col_ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-                unsigned off = (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.pix_stride + b_cv * 8) * 2u;
+                int iy = y0 + oy[t], ix = x0 + ox[t];
+                bool ok = row_ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                unsigned off = (unsigned)(((base + iy) * p.Wi + ix) * p.pix_stride + b_cv * 8) * 2u;
                 b_reg[t][j] = buf_ld_bf16x8(in_rsrc, ok ? off : PDT_OOB_OFFSET);
             }
+            row_advance(pos[j], p);
         }
+        m_b += BKP;
     };
     unsigned char* As = smem;
     unsigned char* Bs = smem + A_BYTES;
@@ -335,11 +382,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(const WgradParams p)
     const int trow0 = 4 * g + q4;
     const int tcol = 4 * pp;
 
-    load_tiles(r_begin);
+    load_tiles();
     for (int ks = 0; ks < nk; ++ks) {
         store_tiles();
         __syncthreads();
-        if (ks + 1 < nk) load_tiles(r_begin + (long long)(ks + 1) * BKP);
+        if (ks + 1 < nk) load_tiles();
 #pragma unroll
         for (int kk = 0; kk < BKP / 32; ++kk) {
             bf16x8 af[MI];
@@ -457,7 +504,10 @@ static int launch_wgrad(WgradParams& p, hipStream_t s, int target_blocks, long l
     p.rows_per_split = rps;
     long long nwg = tiles * split;
     if (nwg > 0x7fffffffLL) return -2;
-    hipLaunchKernelGGL((wgrad_kernel<BMO, BNC, WM, WN>), dim3((unsigned)nwg), dim3(256), 0, s, p);
+    // 1x1 / stride 1 / no padding over a dense input: GEMM row m is input pixel m
+    const bool linear = p.T == 1 && (p.taps[0] & 0xffff) == 0 && p.IS == 1 && p.Hg == p.Hi && p.Wg == p.Wi;
+    if (linear) hipLaunchKernelGGL((wgrad_kernel<BMO, BNC, WM, WN, true>), dim3((unsigned)nwg), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<BMO, BNC, WM, WN, false>), dim3((unsigned)nwg), dim3(256), 0, s, p);
     return launch_fold(p, s);
 }
 
@@ -489,6 +539,12 @@ PDT_API int pdt_conv_wgrad(const void* dy, const void* in, float* dw, long long 
         p.dy_bytes = (unsigned)dy_b;
     }
     p.Hg = Hg; p.Wg = Wg; p.IS = IS; p.N = N; p.ldy = ldy; p.wrow = wrow; p.T = T;
+    {
+        int hw = Hg * Wg;
+        p.step_b = BKP / hw;
+        p.step_y = (BKP % hw) / Wg;
+        p.step_x = (BKP % hw) % Wg;
+    }
     for (int i = 0; i < T; ++i)
         p.taps[i] = ((int)offy[i] & 0xff) | (((int)offx[i] & 0xff) << 8) | ((int)widx[i] << 16);
     for (int i = T; i < MAX_TAPS; ++i) p.taps[i] = 0;

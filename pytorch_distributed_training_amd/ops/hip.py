@@ -596,13 +596,23 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
 
 # Measurement aid (bench/ablate.sh): PDT_ABLATE=wgrad drops every weight-gradient launch, so the step
 # time that remains is what the critical stream costs without its co-runner.  Results are wrong.
-_ABLATE_WGRAD = "wgrad" in os.environ.get("PDT_ABLATE", "").split(",")
+_ABLATE = set(os.environ.get("PDT_ABLATE", "").split(","))
+_ABLATE_WGRAD = "wgrad" in _ABLATE
+_ABLATE_WGRAD_HALF = "wgrad_half" in _ABLATE        # every other launch: what a 2x faster kernel would buy in the step
+_ABLATE_ELEMT = "elemt" in _ABLATE                  # no BatchNorm-backward elementwise pass (bound on fusing it away)
+_ABLATE_APPLY = "apply" in _ABLATE                  # no BatchNorm-forward elementwise pass
+_wgrad_calls = 0
 
 
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, R: int, S: int, stride: int, pad: int, dw: torch.Tensor,
                tile: int = 0, target_blocks: int = 0, atomic_budget_mb: int = 0) -> None:
     if _ABLATE_WGRAD:
         return
+    if _ABLATE_WGRAD_HALF:
+        global _wgrad_calls
+        _wgrad_calls += 1
+        if _wgrad_calls & 1:
+            return
     x = _bf16c(x, "conv_wgrad x")
     dy = _bf16c(dy, "conv_wgrad dy")
     _f32c(dw, "conv_wgrad dw")
@@ -697,6 +707,8 @@ def bn_apply(y, scale, shift, residual, relu: bool, out: Optional[torch.Tensor] 
         residual = _bf16c(residual, "bn_apply residual")
     if bits_out is not None:
         _check_bits(bits_out, y.shape, "bn_apply bits_out")
+    if _ABLATE_APPLY and residual is None:
+        return out
     rc = _lib.pdt_bn_apply(_p(y), _p(scale), _p(shift), _p(residual), _p(out), _p(bits_out), y.numel() // C, C,
                            int(bool(relu)), _stream())
     _check(rc, "pdt_bn_apply")
@@ -785,6 +797,8 @@ def bn_bwd_elemt(g, y, mean, invstd, scale, shift, sums, inv_count: float, mask_
         rc = _lib.pdt_pool_bn_bwd_elemt(_p(g), _p(pool_idx), _p(y), _p(mean), _p(invstd), _p(scale), _p(shift),
                                         _p(sums), inv_count, _p(dx), B, H, W, C, Ho, Wo, _stream())
         _check(rc, "pdt_pool_bn_bwd_elemt")
+        return dx
+    if _ABLATE_ELEMT:
         return dx
     rc = _lib.pdt_bn_bwd_elemt(_p(g), _p(y), _p(mask_src) if mask_mode == MASK_TENSOR else None, _p(mean), _p(invstd),
                                _p(scale), _p(shift), _p(sums), inv_count, _p(dx), y.numel() // C, C, mask_mode,
