@@ -147,7 +147,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(p.dy, (unsigned)((unsigned long long)r_end * (unsigned)p.ldy * 2u));
     const __amdgpu_buffer_rsrc_t in_rsrc =
         make_rsrc(p.in, LINEAR ? (unsigned)((unsigned long long)r_end * (unsigned)p.pix_stride * 2u) : p.in_bytes);
-    bf16x8 a_reg[A_IT], b_reg[B_IT];
+    // two register sets: the loads of K step s+2 are issued before step s is multiplied, so a load has two steps of
+    // MFMA work (not one) to come back before its ds_write needs it
+    bf16x8 a_reg0[A_IT], b_reg0[B_IT], a_reg1[A_IT], b_reg1[B_IT];
     unsigned a_off[A_IT], b_off[B_IT];
     RowPos pos[B_IT];
 #pragma unroll
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     unsigned m_b = r_begin + b_row;                        // GEMM row of this thread's first X row in the coming K step
 
     // branch-free staging loads: rows outside the slice / tile / image read zeros through the range check
-    auto load_tiles = [&]() {
+    auto load_tiles = [&](bf16x8 (&a_reg)[A_IT], bf16x8 (&b_reg)[B_IT]) {
 #pragma unroll
         for (int j = 0; j < A_IT; ++j) {
             a_reg[j] = buf_ld_bf16x8(dy_rsrc, a_off[j]);
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         }
         m_b += BKP;
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, const bf16x8 (&a_reg)[A_IT], const bf16x8 (&b_reg)[B_IT]) {
         unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
         unsigned char* Bs = As + A_BYTES;
 #pragma unroll
@@ -212,14 +214,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     const int trow0 = 4 * g + q4;             // pixel row of read #0 inside a 32-pixel step
     const int tcol = 4 * pp;                  // channel offset inside the 16-channel block
 
-    load_tiles();
-    store_tiles(0);
-    __syncthreads();
-    int cur = 0;
-    for (int ks = 0; ks < nk; ++ks) {
-        const bool has_next = ks + 1 < nk;
-        if (has_next) load_tiles();
-        const unsigned char* As = smem + cur * (A_BYTES + B_BYTES);
+    auto compute = [&](int buf) {
+        const unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
         const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BKP / 32; ++kk) {
@@ -241,9 +237,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (has_next) store_tiles(cur ^ 1);
+    };
+
+    load_tiles(a_reg0, b_reg0);                            // step 0
+    store_tiles(0, a_reg0, b_reg0);
+    if (nk > 1) load_tiles(a_reg0, b_reg0);                // step 1, in flight
+    __syncthreads();
+    for (int ks = 0; ks < nk; ks += 2) {
+        // LDS stage 0 holds step ks, set 0 holds step ks+1 (in flight)
+        if (ks + 2 < nk) load_tiles(a_reg1, b_reg1);
+        compute(0);
+        if (ks + 1 >= nk) break;
+        store_tiles(1, a_reg0, b_reg0);                    // waits for set 0 only: set 1 was requested later
         __syncthreads();
-        cur ^= 1;
+        // LDS stage 1 holds step ks+1, set 1 holds step ks+2 (in flight)
+        if (ks + 3 < nk) load_tiles(a_reg0, b_reg0);
+        compute(1);
+        if (ks + 2 < nk) store_tiles(0, a_reg1, b_reg1);
+        __syncthreads();
     }
 
     const int frow = lane & 15, fq = lane >> 4;
