@@ -233,6 +233,61 @@ PDT_API int pdt_bn_bwd_elemt(const void* g, const void* y, const void* msrc, con
 }
 
 // ------------------------------------------------------------------------------------------
+// GPU-side training augmentation: RandomResizedCrop + horizontal flip of a batch of stored uint8 images.
+//   src [B][S][S][3] uint8, box [B][5] int32 = (x, y, w, h, flip) chosen on the host, dst [B][O][O][3] uint8.
+// Bilinear sampling with half-pixel centres (the arithmetic of F.interpolate(mode="bilinear",
+// align_corners=False) on the cropped box), result rounded to nearest.  One thread per output pixel.
+// The host then never decodes or resizes: it only gathers fixed-size records (memcpy) -- at >13 k images/s
+// per GPU a CPU resize per image would need ~100 cores.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void crop_resize_flip_kernel(const unsigned char* __restrict__ src,
+                                                                const int* __restrict__ box,
+                                                                unsigned char* __restrict__ dst, int B, int S, int O) {
+    const long long total = (long long)B * O * O;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const unsigned iu = (unsigned)idx;                       // total < 2^31 (checked by the launcher)
+    const unsigned t = iu / (unsigned)O;
+    const int ox = (int)(iu - t * (unsigned)O);
+    const int b = (int)(t / (unsigned)O);
+    const int oy = (int)(t - (unsigned)b * (unsigned)O);
+    const int* bx = box + b * 5;
+    const int x0 = bx[0], y0 = bx[1], cw = bx[2], ch = bx[3], flip = bx[4];
+    const int oxs = flip ? O - 1 - ox : ox;
+    float fx = ((float)oxs + 0.5f) * ((float)cw / (float)O) - 0.5f;
+    float fy = ((float)oy + 0.5f) * ((float)ch / (float)O) - 0.5f;
+    fx = fx < 0.0f ? 0.0f : fx;
+    fy = fy < 0.0f ? 0.0f : fy;
+    int ix = (int)fx, iy = (int)fy;
+    const float ax = fx - (float)ix, ay = fy - (float)iy;
+    const int ix1 = ix + 1 < cw ? ix + 1 : cw - 1, iy1 = iy + 1 < ch ? iy + 1 : ch - 1;
+    ix = ix < cw ? ix : cw - 1;
+    iy = iy < ch ? iy : ch - 1;
+    const unsigned char* img = src + (long long)b * S * S * 3;
+    const unsigned char* p00 = img + ((long long)(y0 + iy) * S + x0 + ix) * 3;
+    const unsigned char* p01 = img + ((long long)(y0 + iy) * S + x0 + ix1) * 3;
+    const unsigned char* p10 = img + ((long long)(y0 + iy1) * S + x0 + ix) * 3;
+    const unsigned char* p11 = img + ((long long)(y0 + iy1) * S + x0 + ix1) * 3;
+    unsigned char* o = dst + idx * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float top = (float)p00[c] + ax * ((float)p01[c] - (float)p00[c]);
+        const float bot = (float)p10[c] + ax * ((float)p11[c] - (float)p10[c]);
+        const float v = top + ay * (bot - top);
+        o[c] = (unsigned char)(int)(v + 0.5f);
+    }
+}
+
+PDT_API int pdt_crop_resize_flip(const void* src, const int* box, void* dst, int B, int S, int O, hipStream_t s) {
+    const long long total = (long long)B * O * O;
+    if (B <= 0 || S <= 0 || O <= 0) return 0;
+    if (total >= 0x7fffffffLL) return -2;
+    hipLaunchKernelGGL(crop_resize_flip_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       (const unsigned char*)src, box, (unsigned char*)dst, B, S, O);
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
 // Input transform: loader batch -> zero-haloed NHWC4 bf16 stem input [B][H+6][Wp][4].
 // The stem 7x7/s2/p3 convolution then needs no bounds checks: pixel (h, w) of the image sits
 // at (h+3, w+3); channel 3 is zero.  Source is fp32 NCHW (already normalised) or uint8 NHWC

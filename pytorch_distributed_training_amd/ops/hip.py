@@ -43,6 +43,7 @@ _sig("pdt_bn_apply", _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp)
 _sig("pdt_bn_apply2", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp)
 _sig("pdt_bn_bwd_elemt", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _ll, _i, _i, _vp)
 _sig("pdt_input_pad", _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _vp)
+_sig("pdt_crop_resize_flip", _vp, _vp, _vp, _i, _i, _i, _vp)
 _sig("pdt_maxpool_fwd", _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
 _sig("pdt_bn_relu_maxpool_fwd", _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
 _sig("pdt_maxpool_bwd", _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
@@ -414,6 +415,36 @@ def _moments_from_acc(acc: torch.Tensor, C: int, count: int) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- input / stem
+def _check_boxes(src: torch.Tensor, boxes: torch.Tensor, what: str) -> None:
+    """The kernel indexes the stored image with the box as given: refuse anything that leaves it."""
+    if src.dtype != torch.uint8 or src.dim() != 4 or src.shape[1] != src.shape[2] or src.shape[3] != 3:
+        raise TypeError(f"{what}: expected stored images [B, S, S, 3] uint8, got {tuple(src.shape)} {src.dtype}")
+    if boxes.dtype != torch.int32 or tuple(boxes.shape) != (src.shape[0], 5):
+        raise TypeError(f"{what}: boxes must be int32 [B, 5] = (x, y, w, h, flip)")
+    S = src.shape[1]
+    b = boxes.cpu() if boxes.is_cuda else boxes
+    ok = ((b[:, 0] >= 0) & (b[:, 1] >= 0) & (b[:, 2] >= 1) & (b[:, 3] >= 1) & (b[:, 0] + b[:, 2] <= S)
+          & (b[:, 1] + b[:, 3] <= S) & (b[:, 4] >= 0) & (b[:, 4] <= 1))
+    if not bool(ok.all()):
+        raise ValueError(f"{what}: a crop box leaves the {S} x {S} stored image")
+
+
+def crop_resize_flip(src: torch.Tensor, boxes: torch.Tensor, out_size: int) -> torch.Tensor:
+    """RandomResizedCrop + flip of a stored uint8 batch on the GPU; ``boxes`` is a HOST int32 ``[B, 5]`` tensor
+    (validated here, then copied to the device on the current stream)."""
+    if not src.is_cuda:
+        raise TypeError("crop_resize_flip: the stored images must already be on the GPU")
+    if boxes.is_cuda:
+        raise TypeError("crop_resize_flip: boxes are chosen (and checked) on the host")
+    _check_boxes(src, boxes, "crop_resize_flip")
+    src = src.contiguous()
+    B, S = src.shape[0], src.shape[1]
+    dbox = boxes.contiguous().to(src.device, non_blocking=True)
+    out = torch.empty(B, out_size, out_size, 3, dtype=torch.uint8, device=src.device)
+    _check(_lib.pdt_crop_resize_flip(_p(src), _p(dbox), _p(out), B, S, out_size, _stream()), "pdt_crop_resize_flip")
+    return out
+
+
 def input_transform(img: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """Loader batch (fp32 NCHW normalised, or uint8 NHWC raw) -> zero-haloed NHWC4 bf16 image
     ``[B, H+6, Wp, 4]`` with the picture at offset (3, 3)."""

@@ -73,6 +73,18 @@ def input_transform(img: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, dt
     return _nhwc(img.float()).to(dtype)
 
 
+def crop_resize_flip(src: torch.Tensor, boxes: torch.Tensor, out_size: int) -> torch.Tensor:
+    """``src [B, S, S, 3]`` uint8, ``boxes [B, 5]`` int32 ``(x, y, w, h, flip)`` -> ``[B, out, out, 3]`` uint8:
+    bilinear resize (half-pixel centres, no antialiasing) of each box, then the horizontal flip."""
+    outs = []
+    for img, (x, y, w, h, flip) in zip(src, boxes.tolist()):
+        crop = img[y:y + h, x:x + w].permute(2, 0, 1).unsqueeze(0).float()
+        r = F.interpolate(crop, size=(out_size, out_size), mode="bilinear", align_corners=False)
+        r = (r + 0.5).floor().clamp_(0, 255).to(torch.uint8)[0].permute(1, 2, 0)
+        outs.append(r.flip(1) if flip else r)
+    return torch.stack(outs).contiguous()
+
+
 def prepare_stem_weight(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Compute-side stem weights from the ``[64, 7, 7, 3]`` compute-dtype view (identity here)."""
     return w

@@ -230,6 +230,52 @@ def test_rccl_syncbn_under_list_replay(tmp_path, syncbn_overlap):
     assert res["losses"][-1] < res["losses"][0]                  # same batch five times: the loss must fall
 
 
+def _overlap_worker(port, out_dir, overlap_comm, in_backward, steps=4):
+    """One rank, forced collectives over RCCL, deterministic kernels: the whole training step with the gradient
+    buckets reduced on the communication stream (overlapped with backward) or in line."""
+    from pytorch_distributed_training_amd.config import validate_cfg
+    from pytorch_distributed_training_amd.engine.engines import build_engine
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=dev)
+    cfg = validate_cfg({
+        "dataset": {"name": "synthetic", "n_classes": 100, "image_size": 64},
+        "training": {"optimizer": {"name": "SGD", "lr": 0.05, "weight_decay": 1e-4, "momentum": 0.9},
+                     "lr_schedule": {"name": "constant"}, "train_iters": steps, "batch_size": 16, "sync_bn": True,
+                     "syncbn_comm": "rccl", "bucket_cap_mb": 4.0, "overlap_comm": bool(overlap_comm),
+                     "optimizer_in_backward": bool(in_backward)},
+        "model": {"name": "ResNet18"},
+        "runtime": {"deterministic": True},
+    })
+    torch.manual_seed(5)
+    eng = build_engine(cfg, dev)
+    x, y = _data()
+    x, y = x.cuda(), y.cuda()
+    losses = [float(eng.train_step(x, y)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    m = eng.model
+    torch.save({"losses": losses, "p": m.params.p.cpu(), "rm": m.running_mean.cpu(), "launched": m.reducer.stats["launched"],
+                "overlap": m.reducer.overlap, "nb": len(m.buckets)},
+               os.path.join(out_dir, f"overlap_{int(overlap_comm)}_{int(in_backward)}.pt"))
+    dist.destroy_process_group()
+
+
+def test_overlapped_and_inline_gradient_reduction_train_bit_identically(tmp_path):
+    """``training.overlap_comm`` on / off and the per-bucket optimizer on / off change WHEN buckets are reduced and
+    updated, never what is computed: with the deterministic kernels the parameters after four steps are equal bit for
+    bit (a bucket reduced before its gradients were final, or updated twice, would show here)."""
+    res = {}
+    for overlap, in_bwd in ((1, 1), (0, 1), (1, 0)):
+        _run_ranks(f"_overlap_worker({{port}}, {str(tmp_path)!r}, {overlap}, {in_bwd})", 1, tmp_path, timeout=170,
+                   extra_env={"PDT_FORCE_COLLECTIVES": "1"})
+        res[(overlap, in_bwd)] = torch.load(tmp_path / f"overlap_{overlap}_{in_bwd}.pt")
+    a, b, c = res[(1, 1)], res[(0, 1)], res[(1, 0)]
+    assert a["overlap"] and not b["overlap"] and a["launched"] == b["launched"] == 4 * a["nb"]
+    assert a["losses"] == b["losses"] == c["losses"], (a["losses"], b["losses"], c["losses"])
+    assert torch.equal(a["p"], b["p"]) and torch.equal(a["p"], c["p"])
+    assert torch.equal(a["rm"], b["rm"]) and torch.equal(a["rm"], c["rm"])
+
+
 def _bench(env_extra, launcher):
     env = dict(os.environ)
     env.update(env_extra)
