@@ -23,7 +23,7 @@ _REQUIRED = object()
 # is a sub-section.  ``None`` default means "optional, absent".
 _SCHEMA: Dict[str, Any] = {
     "dataset": {
-        "name": (str, _REQUIRED),              # imagenet | synthetic | synthetic_learnable (brightness encodes the label)
+        "name": (str, _REQUIRED),              # imagenet | packed | synthetic | synthetic_learnable (brightness encodes the label)
         "root": (str, ""),
         "n_classes": (int, _REQUIRED),
         # extensions
@@ -31,6 +31,7 @@ _SCHEMA: Dict[str, Any] = {
         "train_size": (int, 1281167),          # synthetic only: virtual dataset length
         "val_size": (int, 50000),
         "input_format": (str, "float_nchw"),   # float_nchw (upstream contract) | uint8_nhwc
+        "cpu_augment": (bool, False),          # packed only: crop / resize / flip in the loader workers, not on the GPU
     },
     "training": {
         "optimizer": {

@@ -188,16 +188,22 @@ class SyntheticImageNet(Dataset):
 
 def get_dataset(name: str, root: str, split: str, n_classes: int = 1000, image_size: int = 224,
                 fmt: str = "float_nchw", length: Optional[int] = None, seed: int = 0, **kw) -> Dataset:
-    """``name in {"imagenet", "synthetic", "synthetic_learnable"}``, ``split in {"train", "val"}``."""
+    """``name in {"imagenet", "packed", "synthetic", "synthetic_learnable"}``, ``split in {"train", "val"}``.
+
+    ``packed``: ``root`` holds the output of ``python -m pytorch_distributed_training_amd.data.packed``
+    (fixed-size uint8 records, augmentation on the GPU unless ``cpu_augment=True``)."""
     if split not in ("train", "val"):
         raise ValueError(f"split must be 'train' or 'val', got '{split}'")
     lname = name.lower()
     if lname == "imagenet":
         return ImageFolderDataset(root, split, image_size, fmt)
+    if lname == "packed":
+        from .packed import PackedImageDataset
+        return PackedImageDataset(root, split, image_size, fmt, cpu_augment=bool(kw.get("cpu_augment", False)), seed=seed)
     if lname in ("synthetic", "synthetic_learnable"):
         if length is None:
             length = 1281167 if split == "train" else 50000
         if lname == "synthetic_learnable":
             kw["learnable"] = True       # brightness encodes the label: a convergence check without data files
         return SyntheticImageNet(split, length, n_classes, image_size, fmt, seed, **kw)
-    raise ValueError(f"unknown dataset '{name}' (imagenet | synthetic | synthetic_learnable)")
+    raise ValueError(f"unknown dataset '{name}' (imagenet | packed | synthetic | synthetic_learnable)")

@@ -78,10 +78,14 @@ def build_loader(dataset: Dataset, batch_size: int, num_workers: int, train: boo
 
 
 class DevicePrefetcher:
-    """Wraps a batch iterator; keeps one batch in flight to ``device`` on a copy stream."""
+    """Wraps a batch iterator; keeps one batch in flight to ``device`` on a copy stream.
 
-    def __init__(self, it: Iterator, device: torch.device) -> None:
+    ``transform(img, label) -> (img, label)`` (optional) runs on that stream right behind the copy, i.e. under
+    the previous step's compute: the GPU-side augmentation of packed datasets (``data.packed.GpuAugment``)."""
+
+    def __init__(self, it: Iterator, device: torch.device, transform=None) -> None:
         self.it = iter(it)
+        self.transform = transform
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
         self.stream: Optional[torch.cuda.Stream] = torch.cuda.Stream(device=self.device) if self.cuda else None
@@ -96,11 +100,13 @@ class DevicePrefetcher:
             self._next = None
             return
         if not self.cuda:
-            self._next = (img, label)
+            self._next = (img, label) if self.transform is None else self.transform(img, label)
             return
         with torch.cuda.stream(self.stream):
             img = img.to(self.device, non_blocking=True)
             label = label.to(self.device, non_blocking=True)
+            if self.transform is not None:
+                img, label = self.transform(img, label)
             self._event = torch.cuda.Event()
             self._event.record(self.stream)
         self._next = (img, label)

@@ -141,7 +141,7 @@ class PackedImageDataset(Dataset):
                 return torch.from_numpy(np.array(rec)), label          # one copy out of the page cache
             return to_output_format(self.transform(rec), self.fmt), label
         o = (self.side - self.size) // 2
-        return to_output_format(np.ascontiguousarray(rec[o:o + self.size, o:o + self.size]), self.fmt), label
+        return to_output_format(np.array(rec[o:o + self.size, o:o + self.size]), self.fmt), label
 
 
 def random_resized_crop_boxes(n: int, side: int, rng: np.random.Generator, scale=(0.08, 1.0),
@@ -183,7 +183,7 @@ class _CpuCrop:
 
         x, y, w, h, flip = random_resized_crop_boxes(1, rec.shape[0], self.rng)[0]
         im = Image.fromarray(np.asarray(rec)).resize((self.size, self.size), Image.BILINEAR, box=(x, y, x + w, y + h))
-        arr = np.asarray(im, dtype=np.uint8)
+        arr = np.array(im, dtype=np.uint8)
         return np.ascontiguousarray(arr[:, ::-1]) if flip else arr
 
 

@@ -30,7 +30,7 @@ import torch.distributed as dist
 
 from . import checkpoint as ckpt_io
 from .config import validation_loader_settings
-from .data import DevicePrefetcher, build_loader, get_dataset, make_iter_dataloader
+from .data import DevicePrefetcher, GpuAugment, build_loader, get_dataset, make_iter_dataloader
 from .engine.engines import build_engine
 from .logging_utils import worker_logger
 from .optim.schedulers import get_scheduler
@@ -88,8 +88,15 @@ class Trainer:
         fmt = ds_cfg.get("input_format", "float_nchw")
         common = dict(n_classes=ds_cfg["n_classes"], image_size=ds_cfg.get("image_size", 224), fmt=fmt,
                       seed=seed or 0)
-        train_ds = get_dataset(ds_cfg["name"], ds_cfg["root"], "train", length=ds_cfg.get("train_size"), **common)
+        extra = {"cpu_augment": ds_cfg.get("cpu_augment", False)} if ds_cfg["name"].lower() == "packed" else {}
+        train_ds = get_dataset(ds_cfg["name"], ds_cfg["root"], "train", length=ds_cfg.get("train_size"), **common,
+                               **extra)
         val_ds = get_dataset(ds_cfg["name"], ds_cfg["root"], "val", length=ds_cfg.get("val_size"), **common)
+        # packed records are cropped / resized / flipped on the GPU, on the copy stream behind their upload
+        self.gpu_augment = None
+        if getattr(train_ds, "gpu_augment", False):
+            self.gpu_augment = GpuAugment(ds_cfg.get("image_size", 224), seed or 0, info.rank)
+            self._record_side = train_ds.side
 
         self.batch_size = per_process_batch(cfg, info.procs_per_node, info.distributed)
         n_workers = per_process_workers(tr["num_workers"], info.procs_per_node, info.distributed)
@@ -164,8 +171,12 @@ class Trainer:
         tr = self.cfg["training"]
         train_iters = tr["train_iters"]
         per_epoch = max(len(self.train_loader), 1)
+        if self.gpu_augment is not None and self.iter > self.gpu_augment.batches:
+            # resumed run: continue the crop stream where the checkpointed run left it
+            self.gpu_augment.skip(self.iter - self.gpu_augment.batches, self.batch_size, self._record_side)
         batches = DevicePrefetcher(
-            make_iter_dataloader(self.train_loader, self.iter // per_epoch, self.iter % per_epoch), self.device)
+            make_iter_dataloader(self.train_loader, self.iter // per_epoch, self.iter % per_epoch), self.device,
+            transform=self.gpu_augment)
         debug_every = self.cfg["runtime"].get("debug_sync_check", 0)
         fault_iter = int(os.environ.get("FAULT_INJECT_ITER", "-1"))
         fault_rank = int(os.environ.get("FAULT_INJECT_RANK", "0"))

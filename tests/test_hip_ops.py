@@ -481,3 +481,27 @@ def test_fused_sgd_matches_torch(hip, device):
         opt.step()
     assert torch.allclose(p, tp.data, rtol=1e-4, atol=1e-5)
     assert torch.equal(pc, p.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("S,O,B", [(256, 224, 16), (48, 32, 5), (64, 64, 3)])
+def test_crop_resize_flip_kernel_matches_reference(hip, device, S, O, B):
+    """GPU-side RandomResizedCrop + flip against the F.interpolate definition (uint8 results may differ by one
+    count where the fp32 interpolation lands within rounding of .5)."""
+    import numpy as np
+    from pytorch_distributed_training_amd.data.packed import random_resized_crop_boxes
+    g = torch.Generator().manual_seed(3)
+    src = torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8)
+    boxes = torch.from_numpy(random_resized_crop_boxes(B, S, np.random.default_rng(4)))
+    boxes[0] = torch.tensor([0, 0, S, S, 0], dtype=torch.int32)          # whole image
+    boxes[1] = torch.tensor([S - 9, S - 7, 9, 7, 1], dtype=torch.int32)  # tiny box in the far corner, flipped
+    got = hip.crop_resize_flip(src.to(device), boxes, O).cpu()
+    want = ref.crop_resize_flip(src, boxes, O)
+    diff = (got.int() - want.int()).abs()
+    assert got.shape == want.shape and diff.max().item() <= 1, diff.max().item()
+    assert (diff > 0).float().mean().item() < 0.01
+    if S == O:
+        assert torch.equal(got[0], src[0])                                # identity box at the stored size
+    bad = boxes.clone()
+    bad[2] = torch.tensor([S - 4, 0, 8, 8, 0], dtype=torch.int32)         # leaves the image
+    with pytest.raises(ValueError):
+        hip.crop_resize_flip(src.to(device), bad, O)
