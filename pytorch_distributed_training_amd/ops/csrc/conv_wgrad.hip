@@ -25,6 +25,19 @@
 // split x output bytes.
 #include "common.h"
 
+// Measurement switches (read once): PDT_WGRAD_DMA=1 lets the automatic choice use the LDS-DMA 128 x 128 kernel
+// (off by default: inside the training step it measured 0.9 ms slower than the register-staged kernel, because the
+// weight gradients run in the shadow of the critical stream and the DMA version takes more bandwidth from it);
+// PDT_WGRAD_BLOCKS / PDT_WGRAD_ATOMIC_MB override the split-K sizing defaults (1024 workgroups / 24 MB: the step is
+// fastest there -- 512 and 2048 workgroups are both 0.45 ms slower, 12 MB is 1.3 ms slower, 48 MB 0.2 ms).
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+static const int g_pdt_wgrad_dma = env_int("PDT_WGRAD_DMA", 0);
+static const int g_pdt_wgrad_blocks = env_int("PDT_WGRAD_BLOCKS", 1024);   // tuned inside the step, not stand-alone
+static const int g_pdt_wgrad_atomic_mb = env_int("PDT_WGRAD_ATOMIC_MB", 24);
+
 #define MAX_TAPS 52
 #define BKP 64   // pixels per K step
 
@@ -42,6 +55,7 @@ struct WgradParams {
     int splitk;
     long long rows_per_split;
     int step_b, step_y, step_x;        // BKP GEMM rows as (images, grid rows, grid columns): see row_advance
+    int use_dma;                       // 128 x 128 tile: LDS-DMA staging (needs 16-byte aligned pixel rows)
     // one 32-bit word per tap: offy (int8) | offx (int8) << 8 | widx (uint16) << 16.  Sub-dword
     // entries would be fetched with VECTOR loads (no scalar byte loads on gfx9), whose waits
     // drain the tile prefetches; a dword indexed by a wave-uniform tap is one s_load_dword.
@@ -255,6 +269,177 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         compute(1);
         if (ks + 2 < nk) store_tiles(0, a_reg1, b_reg1);
         __syncthreads();
+    }
+
+    const int frow = lane & 15, fq = lane >> 4;
+    const long long wofs = (long long)wi_tap * p.Ci;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            int c = ci0 + wn * WTN + j * 16 + frow;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int n = co0 + wm * WTM + i * 16 + fq * 4 + r;
+                if (n < p.N && c < p.Ci) {
+                    if (p.ws) p.ws[(long long)split * p.slab + (long long)n * p.wrow + wofs + c] = acc[i][j][r];
+                    else atomicAdd(p.dw + (long long)n * p.wrow + wofs + c, acc[i][j][r]);
+                }
+            }
+        }
+}
+
+// LDS-DMA variant of the 128 x 128 tile: both operand tiles go global -> LDS with buffer_load ... lds (no staging
+// registers, no ds_write pass), two stages of 32 KB.  One DMA instruction fills 1 KB = four 256-byte pixel rows; the
+// LDS image is linear, so the bank swizzle of the transposing fragment reads is applied to the per-lane SOURCE address:
+// LDS chunk c (16 bytes = 8 channels) of row r holds source chunk c ^ 2(r & 7).  A ds_read_b64_tr_b16 serves 32 lanes
+// per cycle = 8 consecutive rows x 32 bytes; with that swizzle the 8 rows land in 8 different 32-byte bank groups.
+// Rows past the slice / image / channel range read zeros through the descriptor's range check, which the DMA writes
+// to LDS like any other data.
+typedef __attribute__((address_space(3))) void wg_lds_void_t;
+
+template <bool LINEAR>
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) {
+    constexpr int BMO = 128, BNC = 128, WM = 2, WN = 2;
+    constexpr int ROWB = 256;                              // bytes per LDS row (128 channels)
+    constexpr int A_BYTES = BKP * ROWB, B_BYTES = BKP * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int IT = BKP / 4 / 4;                        // DMA instructions per wave, operand and K step (4 rows each)
+    constexpr int WTM = BMO / WM, WTN = BNC / WN;
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int n_ct = (p.N + BMO - 1) / BMO;
+    const int n_cin = (p.Ci + BNC - 1) / BNC;
+    const int inner = p.T * n_cin;
+    const int nwg = p.splitk * n_ct * inner;
+    int wgid;
+    {
+        int orig = blockIdx.x;
+        int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int in_idx = wgid % inner;
+    const int rest = wgid / inner;
+    const int ct = rest % n_ct;
+    const int split = rest / n_ct;
+    const int tap = in_idx / n_cin;
+    const int cin_tile = in_idx % n_cin;
+    const int co0 = ct * BMO, ci0 = cin_tile * BNC;
+    int oy, ox, wi_tap;
+    unpack_tap(p.taps[__builtin_amdgcn_readfirstlane(tap)], oy, ox, wi_tap);
+
+    const unsigned r_begin = (unsigned)((long long)split * p.rows_per_split);
+    unsigned r_end = r_begin + (unsigned)p.rows_per_split;
+    if (r_end > (unsigned)p.M) r_end = (unsigned)p.M;
+    const int nk = r_begin < r_end ? (int)((r_end - r_begin + BKP - 1) / BKP) : 0;
+    if (nk == 0) return;
+
+    const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(p.dy, (unsigned)((unsigned long long)r_end * (unsigned)p.ldy * 2u));
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        make_rsrc(p.in, LINEAR ? (unsigned)((unsigned long long)r_end * (unsigned)p.pix_stride * 2u) : p.in_bytes);
+
+    // DMA instruction j of this wave fills rows (j * 4 + wave) * 4 + (lane >> 4) of both tiles
+    const int lrow = lane >> 4, lchunk = lane & 15;
+    unsigned a_off[IT], b_off[IT];
+    RowPos pos[IT];
+    unsigned b_colb[IT];                                   // general path: byte offset of this lane's source chunk
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+        const int row = (j * 4 + wave) * 4 + lrow;
+        const int src_chunk = lchunk ^ ((row & 7) * 2);
+        const unsigned m = r_begin + row;
+        const bool a_ok = co0 + src_chunk * 8 < p.N;
+        const bool b_ok = ci0 + src_chunk * 8 < p.Ci;
+        a_off[j] = a_ok ? (m * (unsigned)p.ldy + co0 + src_chunk * 8) * 2u : PDT_OOB_OFFSET;
+        if (LINEAR) {
+            b_off[j] = b_ok ? (m * (unsigned)p.pix_stride + ci0 + src_chunk * 8) * 2u : PDT_OOB_OFFSET;
+        } else {
+            pos[j] = row_pos(m, p.Hg * p.Wg, p.Wg);
+            b_colb[j] = b_ok ? (unsigned)(ci0 + src_chunk * 8) * 2u : PDT_OOB_OFFSET;
+        }
+    }
+    // steps are zero for lanes parked on the out-of-range offset (their chunk lies beyond the channel count)
+    unsigned a_step[IT], b_step[IT];
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+        a_step[j] = a_off[j] == PDT_OOB_OFFSET ? 0u : (unsigned)(BKP * p.ldy * 2);
+        b_step[j] = (!LINEAR || b_off[j] == PDT_OOB_OFFSET) ? 0u : (unsigned)(BKP * p.pix_stride * 2);
+    }
+    unsigned m_b = r_begin + wave * 4 + lrow;              // GEMM row of this lane's first X row in the coming K step
+
+    auto issue = [&](int buf) {
+        unsigned char* As = smem + buf * STAGE;
+        unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dy_rsrc, (wg_lds_void_t*)(As + (j * 4 + wave) * 1024), 16,
+                                                     (int)a_off[j], 0, 0, 0);
+            a_off[j] += a_step[j];
+        }
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            unsigned off;
+            if (LINEAR) {
+                off = b_off[j];
+                b_off[j] += b_step[j];
+            } else {
+                const int iy = pos[j].y * p.IS + oy, ix = pos[j].x * p.IS + ox;
+                const bool ok = m_b + j * 16 < r_end && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi &&
+                                b_colb[j] != PDT_OOB_OFFSET;
+                off = ok ? (unsigned)(((pos[j].b * p.Hi + iy) * p.Wi + ix) * p.pix_stride) * 2u + b_colb[j] : PDT_OOB_OFFSET;
+                row_advance(pos[j], p);
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (wg_lds_void_t*)(Bs + (j * 4 + wave) * 1024), 16, (int)off,
+                                                     0, 0, 0);
+        }
+        m_b += BKP;
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read lane geometry (see wgrad_kernel) with the swizzled chunk position; (row & 7) is the same for
+    // both reads of a pair and for every 32-pixel sub-step, so the column offsets are loop constants
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+    const int trow0 = 4 * g + q4;
+    const int sw = (trow0 & 7) * 2;
+    int acol[MI], bcol[NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acol[i] = (((wm * WTM + i * 16) / 8 + (pp >> 1)) ^ sw) * 16 + (pp & 1) * 8;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bcol[j] = (((wn * WTN + j * 16) / 8 + (pp >> 1)) ^ sw) * 16 + (pp & 1) * 8;
+
+    issue(0);
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        // this wave's share of stage ks has landed ...
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... and every other wave's; all waves are also done reading the other stage (step ks - 1)
+        __builtin_amdgcn_s_barrier();
+        if (ks + 1 < nk) issue(buf ^ 1);
+        const unsigned char* As = smem + buf * STAGE;
+        const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BKP / 32; ++kk) {
+            bf16x8 af[MI], bfr[NI];
+            const int r0 = kk * 32 + trow0, r1 = r0 + 16;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = tr_read_pair(As + r0 * ROWB + acol[i], As + r1 * ROWB + acol[i]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bfr[j] = tr_read_pair(Bs + r0 * ROWB + bcol[j], Bs + r1 * ROWB + bcol[j]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
     }
 
     const int frow = lane & 15, fq = lane >> 4;
@@ -517,6 +702,11 @@ static int launch_wgrad(WgradParams& p, hipStream_t s, int target_blocks, long l
     if (nwg > 0x7fffffffLL) return -2;
     // 1x1 / stride 1 / no padding over a dense input: GEMM row m is input pixel m
     const bool linear = p.T == 1 && (p.taps[0] & 0xffff) == 0 && p.IS == 1 && p.Hg == p.Hi && p.Wg == p.Wi;
+    if (BMO == 128 && BNC == 128 && p.use_dma) {
+        if (linear) hipLaunchKernelGGL((wgrad_dma_kernel<true>), dim3((unsigned)nwg), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((wgrad_dma_kernel<false>), dim3((unsigned)nwg), dim3(256), 0, s, p);
+        return launch_fold(p, s);
+    }
     if (linear) hipLaunchKernelGGL((wgrad_kernel<BMO, BNC, WM, WN, true>), dim3((unsigned)nwg), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((wgrad_kernel<BMO, BNC, WM, WN, false>), dim3((unsigned)nwg), dim3(256), 0, s, p);
     return launch_fold(p, s);
@@ -559,20 +749,33 @@ PDT_API int pdt_conv_wgrad(const void* dy, const void* in, float* dw, long long 
     for (int i = 0; i < T; ++i)
         p.taps[i] = ((int)offy[i] & 0xff) | (((int)offx[i] & 0xff) << 8) | ((int)widx[i] << 16);
     for (int i = T; i < MAX_TAPS; ++i) p.taps[i] = 0;
-    if (target_blocks <= 0) target_blocks = 2048;
-    long long budget = (long long)(atomic_budget_mb > 0 ? atomic_budget_mb : 24) << 20;
+    // tile 8 = tile 1 with LDS-DMA operand staging (the automatic choice where tile 1 would be picked and rows are
+    // 16-byte aligned); a forced tile 1 keeps the register-staged kernel (A/B measurements)
+    p.use_dma = 0;
+    const bool dma_ok = ldy % 8 == 0 && pix_stride % 8 == 0 && Ci % 8 == 0;
+    if (tile == 8) {
+        if (!dma_ok) return -4;
+        p.use_dma = 1;
+        tile = 1;
+    }
+    const bool user_blocks = target_blocks > 0;
+    if (!user_blocks) target_blocks = g_pdt_wgrad_blocks;
+    long long budget = (long long)(atomic_budget_mb > 0 ? atomic_budget_mb : g_pdt_wgrad_atomic_mb) << 20;
     if (tile == 0) {
         if (Ci <= 32) tile = (T == 7) ? 5 : 3;
         else if (T == 9 && Ci <= 64) tile = (N <= 64) ? 6 : 7;    // 3x3 on 64 channels: one kernel row per workgroup
         else if (N <= 64 || Ci <= 64) tile = 2;
-        else tile = 1;
+        else {
+            tile = 1;
+            p.use_dma = dma_ok && g_pdt_wgrad_dma;
+        }
     }
     switch (tile) {
         case 1: return launch_wgrad<128, 128, 2, 2>(p, s, target_blocks, budget, ws_slabs);
         case 2: return launch_wgrad<64, 64, 2, 2>(p, s, target_blocks, budget, ws_slabs);
         case 3: return launch_wgrad<64, 32, 2, 2>(p, s, target_blocks, budget, ws_slabs);
         case 4: return launch_wgrad<128, 64, 2, 2>(p, s, target_blocks, budget, ws_slabs);
-        case 5: return launch_wgrad_taps<64, 32, 2, 2, 7>(p, s, target_blocks < 2048 ? target_blocks : 768, ws_slabs);
+        case 5: return launch_wgrad_taps<64, 32, 2, 2, 7>(p, s, user_blocks ? target_blocks : 768, ws_slabs);
         case 6: return launch_wgrad_taps<64, 64, 2, 2, 3>(p, s, target_blocks, ws_slabs);
         case 7: return launch_wgrad_taps<128, 64, 2, 2, 3>(p, s, target_blocks, ws_slabs);
         default: return -6;

@@ -147,6 +147,9 @@ WGRAD = [
     (16, 56, 64, 256, 1, 1, 0, 0), (64, 56, 64, 64, 3, 1, 1, 0), (64, 28, 128, 128, 3, 1, 1, 1),
     (64, 28, 512, 128, 1, 1, 0, 1), (64, 14, 256, 256, 3, 1, 1, 1), (64, 14, 1024, 256, 1, 1, 0, 2),
     (16, 56, 128, 128, 3, 2, 1, 0), (64, 7, 512, 2048, 1, 1, 0, 0), (64, 28, 256, 512, 1, 2, 0, 0),
+    # tile 8: the LDS-DMA 128 x 128 kernel forced (linear 1x1, 3x3 with padding taps, stride 2, channel remainders)
+    (64, 14, 1024, 256, 1, 1, 0, 8), (64, 14, 256, 256, 3, 1, 1, 8), (16, 56, 128, 128, 3, 2, 1, 8),
+    (64, 28, 256, 512, 1, 2, 0, 8), (16, 28, 192, 320, 1, 1, 0, 8), (8, 14, 136, 200, 3, 1, 1, 8),
 ]
 
 
