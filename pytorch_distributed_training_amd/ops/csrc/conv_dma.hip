@@ -477,8 +477,9 @@ static int g1_launch(const ConvDmaParams& p, hipStream_t s) {
     return pdt_launch_status();
 }
 
-// tile: 0 = auto (3 when N is a multiple of 128, else 4); 1 = 128 x 128, 2 = 128 x 64 (both: K slices of 32, four-stage
-// ring); 3 = 128 x 128 with K slices of 64 and two stages, 4 = 128 x 64 with K slices of 64 and three stages
+// tile: 0 = auto (3 when N is a multiple of 128, else 4); 3 = 128 x 128 with K slices of 64 and two stages, 4 = 128 x 64
+// with K slices of 64 and three stages (1 / 2 are old names of 3 / 4); 5 = 128 x 64 with K slices of 32 and four stages,
+// for operands with 32 channels per tap (the stem), never chosen automatically
 PDT_API int pdt_conv_dma(const void* in, const void* wgt, void* out, const void* addend, int addend_half,
                          const void* mask_bits, float* stat_acc, const float* stat_shift, const void* bstat_y,
                          const float* bstat_mean, const float* bstat_scale, const float* bstat_shift, long long M, int Hi,
@@ -487,9 +488,17 @@ PDT_API int pdt_conv_dma(const void* in, const void* wgt, void* out, const void*
                          const unsigned short* widx, int tile, hipStream_t s) {
     if (T <= 0 || T > DMA_MAX_TAPS) return -3;
     if (M <= 0) return 0;
-    if (M >= 0x7fffffffLL || N < 64 || N % 64 != 0 || Ci < 64 || Ci % 64 != 0 || pix_stride < Ci || pix_stride % 8 != 0 ||
-        wrow < T * Ci)
+    if (M >= 0x7fffffffLL || N < 64 || N % 64 != 0 || wrow < T * Ci) return -4;
+    if (tile == 5) {
+        // K slices of 32 over a gathered operand whose "pixels" may overlap (the stem reads 32 consecutive values of its
+        // packed NHWC4 image per tap: pix_stride 4, Ci 32): every DMA source address must still be 16-byte aligned
+        if (Ci < 32 || Ci % 32 != 0 || bstat_y || addend || mask_bits) return -4;
+        if ((IS * pix_stride) % 8 != 0 || (Wi * pix_stride) % 8 != 0) return -4;
+        for (int i = 0; i < T; ++i)
+            if (((int)offx[i] * pix_stride) % 8 != 0) return -4;
+    } else if (Ci < 64 || Ci % 64 != 0 || pix_stride < Ci || pix_stride % 8 != 0) {
         return -4;
+    }
     if (bstat_y && (!stat_acc || !bstat_mean || (bstat_scale && !bstat_shift))) return -8;
     if (Hg <= 0 || Wg <= 0 || IS < 1 || OS < 1 || M % ((long long)Hg * Wg) != 0) return -5;
     if (addend && addend_half && ((Ho | Wo) & 1)) return -10;
@@ -525,6 +534,7 @@ PDT_API int pdt_conv_dma(const void* in, const void* wgt, void* out, const void*
     switch (tile) {
         case 3: return bs ? g1_launch<128, 2, 2, 64, 2, true>(p, s) : g1_launch<128, 2, 2, 64, 2, false>(p, s);
         case 4: return bs ? g1_launch<64, 4, 1, 64, 3, true>(p, s) : g1_launch<64, 4, 1, 64, 3, false>(p, s);
+        case 5: return g1_launch<64, 4, 1, 32, 4, false>(p, s);       // 128 x 64, K slices of 32, ring of 4: the stem
         default: return -6;
     }
 }

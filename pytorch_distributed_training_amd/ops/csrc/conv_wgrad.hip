@@ -37,6 +37,7 @@ static int env_int(const char* name, int dflt) {
 static const int g_pdt_wgrad_dma = env_int("PDT_WGRAD_DMA", 0);
 static const int g_pdt_wgrad_blocks = env_int("PDT_WGRAD_BLOCKS", 1024);   // tuned inside the step, not stand-alone
 static const int g_pdt_wgrad_atomic_mb = env_int("PDT_WGRAD_ATOMIC_MB", 24);
+static const int g_pdt_wgrad_big_tile = env_int("PDT_WGRAD_BIG_TILE", 1);      // tile of the layers with N, Ci > 64
 
 #define MAX_TAPS 52
 #define BKP 64   // pixels per K step
@@ -766,8 +767,8 @@ PDT_API int pdt_conv_wgrad(const void* dy, const void* in, float* dw, long long 
         else if (T == 9 && Ci <= 64) tile = (N <= 64) ? 6 : 7;    // 3x3 on 64 channels: one kernel row per workgroup
         else if (N <= 64 || Ci <= 64) tile = 2;
         else {
-            tile = 1;
-            p.use_dma = dma_ok && g_pdt_wgrad_dma;
+            tile = g_pdt_wgrad_big_tile;
+            p.use_dma = tile == 1 && dma_ok && g_pdt_wgrad_dma;
         }
     }
     switch (tile) {

@@ -365,6 +365,7 @@ def _wgrad(dy, inp, dw, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow, tap
 _USE_CONV_DMA = os.environ.get("PDT_CONV_DMA", "1") == "1"
 _DMA_TILE = int(os.environ.get("PDT_DMA_TILE", "0"))          # measurement override of the DMA kernel's tile choice
 _DMA_TAPS = os.environ.get("PDT_CONV_DMA_TAPS", "1") == "1"   # 0: only single-tap (1x1) launches use the DMA kernel
+_STEM_DMA = os.environ.get("PDT_STEM_DMA", "1") == "1"        # 0: the stem convolution stays on the register-staged kernel
 
 
 class PendingStats:
@@ -503,8 +504,16 @@ def stem_fprop(x0: torch.Tensor, wp: torch.Tensor, stat_shift: Optional[torch.Te
     y = torch.empty(B, Ho, Wo, Co, dtype=torch.bfloat16, device=x0.device)
     M = B * Ho * Wo
     acc = _accumulator(x0.device, Co, "stats") if stat_shift is not None else None
-    _igemm(x0, wp, y, M, Hp, Wp, 4, 32, Ho, Wo, 2, Ho, Wo, 1, 0, 0, Co, Co, 7 * 32, _stem_taps(),
-           stat_acc=acc, stat_shift=stat_shift)
+    taps = _stem_taps()
+    if _USE_CONV_DMA and _STEM_DMA and Co % 64 == 0 and x0.numel() * 2 < 0x7fff0000:
+        # the LDS-DMA kernel with K slices of 32 (one tap = one slice of the packed image)
+        rc = _lib.pdt_conv_dma(_p(x0), _p(wp), _p(y), None, 0, None, _p(acc), _p(stat_shift), None, None, None, None, M,
+                               Hp, Wp, 4, 32, Ho, Wo, 2, Ho, Wo, 1, 0, 0, Co, 7 * 32, taps.T, taps.offy, taps.offx,
+                               taps.widx, 5, _stream())
+        _check(rc, "pdt_conv_dma (stem)")
+    else:
+        _igemm(x0, wp, y, M, Hp, Wp, 4, 32, Ho, Wo, 2, Ho, Wo, 1, 0, 0, Co, Co, 7 * 32, taps,
+               stat_acc=acc, stat_shift=stat_shift)
     if acc is None:
         return y, None
     return y, (PendingStats(acc, Co, M) if defer_stats else _moments_from_acc(acc, Co, M))
