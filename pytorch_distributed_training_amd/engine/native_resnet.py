@@ -205,6 +205,10 @@ class NativeResNet:
             prio = os.environ.get("PDT_WGRAD_PRIO")
             self._wgrad_stream = torch.cuda.Stream(device=self.device, **({"priority": int(prio)} if prio else {}))
             self._fork_event, self._join_event = ops.new_event(), ops.new_event()
+        # With an overlapped reducer the communication stream waits for the weight-gradient stream at every bucket;
+        # otherwise the main stream joins it there itself.  PDT_WGRAD_JOIN=1 forces the joins (A/B measurements).
+        self._reducer_waits_wgrad = (self._wgrad_stream is not None and os.environ.get("PDT_WGRAD_JOIN", "0") != "1"
+                                     and self.reducer.add_producer_stream(self._wgrad_stream))
         self._rec = None                 # program being recorded (StepProgram / ListProgram), else None
         self.replay_failures = 0
         self._plans: Dict[tuple, object] = {}
@@ -672,7 +676,7 @@ class NativeResNet:
                 with torch.cuda.stream(ws):
                     ops.conv_wgrad(x, dy, u.ksize, u.ksize, u.stride, u.pad, P.grad(key))
                 self._wgrad_keep.append((x, dy))       # their memory must outlive the side-stream kernel
-                if final and red.completes_bucket(end):
+                if final and red.completes_bucket(end) and not self._reducer_waits_wgrad:
                     self._join_wgrad()
             if final:                                  # (a batch slice: the gradient is not complete yet)
                 self._mark_ready(end)

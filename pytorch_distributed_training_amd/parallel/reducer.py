@@ -20,6 +20,8 @@ Design for an xGMI mesh of MI355X GPUs:
   when backward ends only the last (small) bucket and its slice of the update are still to
   run -- the whole-model optimizer pass no longer sits serially behind backward.  With a hook
   the pipeline also runs in a one-rank job (no collective, only the hook on the side stream);
+* gradients written on a second compute stream (the engine's weight-gradient stream) are waited for by the
+  communication stream, not by the main compute stream (:meth:`GradReducer.add_producer_stream`);
 * the ``1/world_size`` average is not applied here: the fused optimizer kernel folds it
   into its gradient read (``grad_scale``);
 * ``comm_dtype=torch.bfloat16`` halves the bytes on the links: the bucket is rounded to bf16,
@@ -59,6 +61,8 @@ class GradReducer:
         self._ready_events: List = []
         self._done_events: List = []
         self._timing: Optional[list] = None
+        self._producers: list = []            # streams besides the current one that write gradients (see below)
+        self._producer_events: List[list] = []
         self.stats = {"launched": 0, "bytes": 0, "steps": 0}
 
     # ---------------------------------------------------------------------------------
@@ -70,11 +74,23 @@ class GradReducer:
     def set_bucket_hook(self, hook: Optional[Callable[[int, int], None]]) -> None:
         self.bucket_hook = hook
 
+    def add_producer_stream(self, stream) -> bool:
+        """Gradients are also written by kernels on ``stream`` (the engine's weight-gradient stream).  With the
+        overlapped GPU path the COMMUNICATION stream then waits for that stream at every bucket, so the compute
+        stream never has to (a join there stalls the critical path until the weight gradients have caught up).
+        Returns False when this reducer cannot take the dependency over (the caller keeps joining itself)."""
+        if not (self.is_cuda and self.overlap):
+            return False
+        self._producers.append(stream)
+        return True
+
     def _ensure_streams(self) -> None:
         if self.is_cuda and self.overlap and self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=self.flat.device)
             self._ready_events = [torch.cuda.Event() for _ in self.buckets]
             self._done_events = [torch.cuda.Event() for _ in self.buckets]
+        if self.is_cuda and self.overlap and len(self._producer_events) != len(self.buckets):
+            self._producer_events = [[torch.cuda.Event() for _ in self._producers] for _ in self.buckets]
 
     def begin_step(self) -> None:
         self._next = 0
@@ -104,8 +120,12 @@ class GradReducer:
             self._ensure_streams()
             cur = torch.cuda.current_stream(self.flat.device)
             self._ready_events[idx].record(cur)
+            for ev, producer in zip(self._producer_events[idx], self._producers):
+                ev.record(producer)
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(self._ready_events[idx])
+                for ev in self._producer_events[idx]:
+                    self._comm_stream.wait_event(ev)
                 if self.collective:
                     self._all_reduce(view)
                 if self.bucket_hook is not None:
