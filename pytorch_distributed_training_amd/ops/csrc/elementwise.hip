@@ -737,8 +737,12 @@ PDT_API int pdt_zero_f32(float* p, long long n, hipStream_t s) {
 }
 
 PDT_API int pdt_event_create(void** out) {
+    // The events only order streams of one device against each other: no timestamps, and no system-scope fence (a
+    // device-scope release is all the waiting stream needs; the system-scope one writes the L2 back at every record).
+    // PDT_EVENT_SYSTEM_FENCE=1 restores the default fence (A/B measurements).
+    static const bool fence = [] { const char* v = getenv("PDT_EVENT_SYSTEM_FENCE"); return v && v[0] == '1'; }();
     hipEvent_t ev;
-    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming | (fence ? 0u : hipEventDisableSystemFence));
     if (e != hipSuccess) return (int)e;
     *out = (void*)ev;
     return 0;
