@@ -52,6 +52,30 @@ __global__ void zero_floats_kernel(float* p, int n) {
 }
 
 
+// N accumulator elements at once: every load of all N elements is in flight before the first store, so a thread pays
+// one memory round trip for them instead of N (these folds are single-workgroup kernels on the critical path of every
+// layer: their time IS round trips).  Elements with ok[n] false are skipped.
+template <int N>
+__device__ __forceinline__ void acc_take_n(float* const (&p)[N], const bool (&ok)[N], size_t stride, int nrep,
+                                           float (&out)[N]) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) out[n] = 0.0f;
+    for (int r0 = 0; r0 < nrep; r0 += NREP) {
+        float v[N][NREP];
+#pragma unroll
+        for (int n = 0; n < N; ++n)
+#pragma unroll
+            for (int r = 0; r < NREP; ++r) v[n][r] = ok[n] ? p[n][(size_t)(r0 + r) * stride] : 0.0f;
+#pragma unroll
+        for (int n = 0; n < N; ++n)
+#pragma unroll
+            for (int r = 0; r < NREP; ++r) {
+                out[n] += v[n][r];
+                if (ok[n]) p[n][(size_t)(r0 + r) * stride] = 0.0f;
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Column reduce skeleton
 // ------------------------------------------------------------------------------------------
@@ -386,13 +410,18 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(float* __restrict__ ac
                                                            float* __restrict__ dbeta, int C, int nrep) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float s0 = acc_take(acc + c, (size_t)2 * C, nrep);
-    float s1 = acc_take(acc + C + c, (size_t)2 * C, nrep);
-    s1 *= invstd[c];
+    // everything this thread reads is requested before anything is written: one round trip
+    const float is = invstd[c];
+    const float db = dbeta ? dbeta[c] : 0.0f, dg = dgamma ? dgamma[c] : 0.0f;
+    float* ptr[2] = {acc + c, acc + C + c};
+    const bool ok[2] = {true, true};
+    float t[2];
+    acc_take_n<2>(ptr, ok, (size_t)2 * C, nrep, t);
+    const float s0 = t[0], s1 = t[1] * is;
     sums[c] = s0;
     sums[C + c] = s1;
-    if (dbeta) dbeta[c] += s0;
-    if (dgamma) dgamma[c] += s1;
+    if (dbeta) dbeta[c] = db + s0;
+    if (dgamma) dgamma[c] = dg + s1;
 }
 
 // fused: replicas -> local sums (+ local dgamma / dbeta) -> exchange over the ranks -> sums
@@ -403,13 +432,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_sums_fused_kernel(const CarDev ca
     __shared__ float vals[CAR_MAX_FLOATS];
     __shared__ unsigned ctl[2];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float s0 = acc_take(acc + c, (size_t)2 * C, nrep);
-        float s1 = acc_take(acc + C + c, (size_t)2 * C, nrep);
-        s1 *= invstd[c];
+        const float is = invstd[c];
+        const float db = dbeta ? dbeta[c] : 0.0f, dg = dgamma ? dgamma[c] : 0.0f;
+        float* ptr[2] = {acc + c, acc + C + c};
+        const bool ok[2] = {true, true};
+        float t[2];
+        acc_take_n<2>(ptr, ok, (size_t)2 * C, nrep, t);
+        const float s0 = t[0], s1 = t[1] * is;
         vals[c] = s0;
         vals[C + c] = s1;
-        if (dbeta) dbeta[c] += s0;          // local: the gradient buckets are summed over the ranks later
-        if (dgamma) dgamma[c] += s1;
+        if (dbeta) dbeta[c] = db + s0;      // local: the gradient buckets are summed over the ranks later
+        if (dgamma) dgamma[c] = dg + s1;
     }
     __syncthreads();
     car_exchange_block(car, vals, 2 * C, ctl);      // after a timeout: NaN sums, status set
