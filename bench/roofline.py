@@ -69,7 +69,17 @@ def _entry(name, a):
         return _igemm_entry(name, a)
     if name == "pdt_conv_dma":
         return _conv_dma_entry(a)
-    if name == "pdt_conv_wgrad":
+    if name == "pdt_conv_dma_ex":            # + second operand (row-aligned, Ci2 channels) and accumulator start values
+        e = _conv_dma_entry(a)
+        M, N = a[12], a[25]
+        in2, Ci2, ps2 = a[32], a[33], a[34]
+        if in2:
+            e["bytes"] += M * ps2 * 2
+            e["flops"] += 2 * M * N * Ci2
+            e["kind"] = e["kind"].replace("igemm", "igemm2")
+            e["desc"] = e["desc"].replace(" (dma)", f"+{Ci2} (dma)")
+        return e
+    if name in ("pdt_conv_wgrad", "pdt_conv_wgrad_ex"):
         dy, inp, dw, M, Hi, Wi, ps, Ci, Hg, Wg, IS, N, ldy, wrow, T = a[:15]
         images = M // max(Hg * Wg, 1)
         return dict(kind="wgrad", bytes=M * ldy * 2 + images * Hi * Wi * ps * 2 + N * wrow * 4,
@@ -115,7 +125,8 @@ def _entry(name, a):
 # library call -> substring of the kernel name it launches (None: no kernel, e.g. a stream wait)
 KERNEL_OF = {
     "pdt_conv_igemm": "igemm_kernel", "pdt_conv_igemm_bstats": "igemm_kernel", "pdt_conv_wgrad": "wgrad_",
-    "pdt_conv_dma": "conv_dma_kernel",
+    "pdt_conv_dma": "conv_dma_kernel", "pdt_conv_dma_ex": "conv_dma_kernel", "pdt_conv_wgrad_ex": "wgrad_",
+    "pdt_bnfold_prepare": "bnfold_prepare_kernel", "pdt_bnfold_wgrad": "bnfold_wgrad_kernel",
     "pdt_bn_apply": "bn_apply_kernel", "pdt_bn_apply2": "bn_apply2_kernel", "pdt_bn_bwd_elemt": "bn_bwd_elemt_kernel",
     "pdt_bn_bwd_reduce_accum": "bn_bwd_reduce_kernel", "pdt_bn_stats_accum": "bn_stats_kernel",
     "pdt_bn_moments": "bn_moments_kernel", "pdt_bn_finalize": "bn_finalize_kernel",

@@ -184,6 +184,16 @@ class NativeResNet:
         self._relu_bits = bool(getattr(ops, "relu_bits", False)) and os.environ.get("PDT_RELU_BITS", "1") == "1"
         self._relu_bits_only = bool(getattr(ops, "bwd_stats_need_bits", False))
         self._half_addend = bool(getattr(ops, "half_addend", False)) and os.environ.get("PDT_HALF_ADDEND", "1") == "1"
+        # BatchNorm backward of a bottleneck block's last unit folded into the gradient products of its 1x1
+        # convolution: the widest gradient tensor of the block is never written (see _folded_tail_backward).
+        self._bn_fold = bool(getattr(ops, "bn_fold", False)) and os.environ.get("PDT_BN_FOLD", "1") == "1"
+        # ... where the tensor it avoids is large: the fold costs a few small kernels and a C x C Gram product per
+        # layer.  At batch 512 it wins clearly on the 56x56 and 28x28 stages (822 / 411 MB avoided; stand-alone
+        # 933 -> 589 and 474 -> 376 us per block, bench/fold_layers.py), is even on the 14x14 stage (205 MB: 5 % slower
+        # stand-alone, 0.1 ms faster inside the step, where the elementwise pass shares the chip with the weight
+        # gradients) and loses on the 7x7 stage (103 MB).
+        self._bn_fold_min_bytes = int(float(os.environ.get("PDT_BN_FOLD_MIN_MB", "150")) * 2 ** 20) \
+            if self.device.type == "cuda" else 0
         # Step replay (see .graphs): the second step of a batch signature is recorded, later ones
         # replay the record.  "list": a command list of the backend's own launches (default);
         # "graph": HIP graphs separated by host actions.  PDT_HIP_GRAPHS: 0 = off, 1 = on,
@@ -705,6 +715,56 @@ class NativeResNet:
         # (the deferred weight-gradient closures of the RCCL overlap mode are whole-layer units)
         return self._slice_bytes > 0 and not (self.sync_bn and self.syncbn_overlap and self._xgmi is None)
 
+    def _can_fold(self, u: ConvBNSpec, y: torch.Tensor) -> bool:
+        """The unit's BatchNorm backward is folded into its convolution's gradient products: a 1x1 / stride 1
+        convolution with channel counts the kernels take (every bottleneck block's last unit) whose output
+        ``y`` is large enough for the fold to pay."""
+        if not self._bn_fold or u.ksize != 1 or u.stride != 1 or u.pad != 0:
+            return False
+        if y.numel() * y.element_size() < self._bn_fold_min_bytes:
+            return False
+        if getattr(self.ops, "name", "") != "hip":
+            return True
+        return u.cin % 64 == 0 and u.cout % 64 == 0 and u.cin <= self.ops.BN_FOLD_MAX_C
+
+    def _folded_wgrad_fn(self, u: ConvBNSpec, x: torch.Tensor, g: torch.Tensor, fold):
+        """Like :meth:`_conv_wgrad_fn`, for a unit whose BatchNorm backward is folded (``g`` is the gradient
+        w.r.t. the BatchNorm output)."""
+        P, ops, red = self.params, self.ops, self.reducer
+        key = f"{u.conv}.weight"
+
+        def run() -> None:
+            end = P.end_offset(key)
+            ws = self._wgrad_stream
+            if ws is None:
+                ops.conv_wgrad_folded(x, g, fold, P.compute(key), P.grad(key))
+            else:
+                cur = torch.cuda.current_stream(self.device).cuda_stream
+                ops.stream_wait_stream(ws.cuda_stream, cur, self._fork_event)
+                with torch.cuda.stream(ws):
+                    ops.conv_wgrad_folded(x, g, fold, P.compute(key), P.grad(key))
+                self._wgrad_keep.append((x, g, *fold.tensors()))   # must outlive the side-stream kernels
+                if red.completes_bucket(end) and not self._reducer_waits_wgrad:
+                    self._join_wgrad()
+            self._mark_ready(end)
+        return run
+
+    def _folded_tail_backward(self, u: ConvBNSpec, prev_u: ConvBNSpec, ctx: _UnitCtx, g: torch.Tensor,
+                              prereduced: bool) -> torch.Tensor:
+        """Backward of a bottleneck block's last unit (1x1 convolution + BatchNorm) WITHOUT the gradient w.r.t.
+        the convolution output: that tensor has 4x the channels of the unit's input, and the elementwise pass
+        that writes it plus the two kernels that read it back are a quarter of the block's backward traffic.
+        The convolution output is itself a product with the weights, so the BatchNorm-backward terms move into
+        small per-step matrices (``ops.bn_fold_prepare``) and both gradient products read ``g`` and the unit's
+        INPUT instead (``ops.conv_dgrad_folded`` / ``ops.conv_wgrad_folded``)."""
+        P, ops = self.params, self.ops
+        sums = self._bn_backward_sums(u, ctx, g, None, MASK_NONE, prereduced)
+        key = f"{u.conv}.weight"
+        fold = ops.bn_fold_prepare(sums, ctx.scale, ctx.invstd, ctx.mean, 1.0 / ctx.count, P.compute(key),
+                                   self._wt_view(key))
+        self._wgrad(self._folded_wgrad_fn(u, ctx.x_in, g, fold))
+        return ops.conv_dgrad_folded(g, ctx.x_in, fold, **(self._bstats(prev_u, MASK_RECOMPUTE) or {}))
+
     def _sliced_tail_backward(self, u: ConvBNSpec, prev_u: ConvBNSpec, ctx: _UnitCtx, g: torch.Tensor,
                               prereduced: bool) -> torch.Tensor:
         """Backward of a block's last unit in batch slices: the BatchNorm elementwise pass writes a
@@ -754,6 +814,9 @@ class NativeResNet:
         for i in range(last, -1, -1):
             u = b.units[i]
             ctx = self._ctx.pop(u.bn)
+            if i == last and i > 0 and self._can_fold(u, ctx.y):
+                cur = self._folded_tail_backward(u, b.units[i - 1], ctx, cur, g_prereduced)
+                continue
             if i == last and i > 0 and self._can_slice_bwd() and self._n_slices(ctx.y) > 1:
                 cur = self._sliced_tail_backward(u, b.units[i - 1], ctx, cur, g_prereduced)
                 continue

@@ -36,7 +36,8 @@ CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libpdt_hip.so")
 ARCH = "gfx950"
-SOURCES = ["elementwise.hip", "reduce.hip", "conv_igemm.hip", "conv_dma.hip", "conv_wgrad.hip", "xgmi_allreduce.hip"]
+SOURCES = ["elementwise.hip", "reduce.hip", "conv_igemm.hip", "conv_dma.hip", "conv_wgrad.hip", "bn_fold.hip",
+           "xgmi_allreduce.hip"]
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wno-unused-result"]
 REMARKS = ["-Rpass-analysis=kernel-resource-usage"]
 ASAN_LIB = os.path.join(HERE, "libpdt_hip_asan.so")

@@ -32,9 +32,17 @@
 // Epilogue options (the same contract as conv_igemm.hip): per-channel BatchNorm statistics of the
 // stored values (forward), "out = (out + addend) * mask" with the addend at full or half resolution
 // and the mask as one bit per element, BatchNorm-backward sums of the layer that consumes the result.
+//
+// Second operand (1x1 / stride 1 geometry only): after the taps the reduction continues over Ci2 channels of
+// a second tensor whose row m is GEMM row m, against weight columns [T*Ci, T*Ci + Ci2); and the accumulators
+// may start from a per-output-channel constant instead of zero.  Together they evaluate
+//   out = in . W1^T + in2 . W2^T + bias
+// in one pass, which is how a BatchNorm backward is folded into the data gradient of the 1x1 convolution
+// in front of it (bn_fold.hip): no normalised-gradient tensor is ever written.
 #include "common.h"
 
 #define DMA_MAX_TAPS 52
+#define DMA_MAX_BIAS 512
 
 struct ConvDmaParams {
     const bf16* in;
@@ -57,6 +65,10 @@ struct ConvDmaParams {
     int simple_out;                    // output row == GEMM row
     int addend_half;                   // addend is [B][Ho/2][Wo/2][N], present at even output (y, x) only
     int nrep;                          // replica rows of the statistics accumulator (see common.h)
+    const bf16* in2;                   // second operand [M][pix_stride2] (may be null), reduced after the taps
+    const float* bias;                 // [N] start value of the accumulators (may be null; N <= DMA_MAX_BIAS)
+    unsigned in2_bytes;
+    int Ci2, pix_stride2;
     int taps[DMA_MAX_TAPS];            // offy (int8) | offx (int8) << 8 | widx (uint16) << 16
 };
 
@@ -100,7 +112,9 @@ __device__ __forceinline__ int g1_swz(int row) {
     return BK == 64 ? ((row >> 1) & 7) : ((row >> 1) & 2);
 }
 
-template <int BN, int WM, int WN, int BK, int R, bool BSTAT>
+// FOLD: the launch has a second operand and/or accumulator start values (its own instantiations, so the plain
+// kernels carry neither the extra scalar registers nor the extra LDS)
+template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD = false>
 __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p) {
     constexpr int BM = 128, RB = BK * 2;
     constexpr int CH = BK / 8;                              // 16-byte chunks per LDS row
@@ -116,8 +130,15 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
     constexpr int KS = BK / 32;
     static_assert(A_DMA >= 1 && B_DMA >= 1, "every wave takes part in filling both operands");
 
+    // One array for everything (a second __shared__ object next to the DMA ring makes the compiler drain the ring
+    // before every fragment read), and not a byte more than this: two workgroups of 66 KB share a CU, two of 68 KB
+    // do not (measured: the kernel then runs at half residency, whatever the occupancy query says).  The
+    // accumulator start values therefore live in the statistics hand-over area and are staged again after each
+    // (rare) statistics flush.
+    static_assert(DMA_MAX_BIAS * 4 <= 4 * 2 * 64 * 4, "accumulator start values share the statistics hand-over area");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[R * STAGE + 4 * 2 * 64 * 4];
     float* red = reinterpret_cast<float*>(smem + R * STAGE);       // [wave][2][64] statistics hand-over
+    float* bias_lds = red;                                         // [N] accumulator start values between flushes
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,11 +149,15 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
     const int n_tiles_m = (p.M + BM - 1) / BM;
     const int nwg = n_tiles_m * n_tiles_n;
     const int kc = p.Ci / BK;                 // K steps per tap
-    const int nk = p.T * kc;
+    const int kc2 = FOLD ? p.Ci2 / BK : 0;    // K steps of the second operand (0: none)
+    const int kdiff = kc2 - kc;
+    const int nphase = p.T + (kc2 > 0 ? 1 : 0);
+    const int nk = p.T * kc + kc2;
     const int HgWg = p.Hg * p.Wg;
 
     const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.in, p.in_bytes);
     const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.wgt, p.wgt_bytes);
+    const __amdgpu_buffer_rsrc_t a2_rsrc = make_rsrc(FOLD ? p.in2 : nullptr, FOLD ? p.in2_bytes : 0u);
 
     auto tile_origin = [&](int v, int& m0, int& n0) {
         // XCD-aware bijective remap: ids v, v+8, ... run on one XCD; give each XCD a contiguous range of tiles
@@ -175,24 +200,38 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
         if (iv >= nwg) return false;
         unsigned char* As = smem + ibuf * STAGE;
         unsigned char* Bs = As + A_BYTES;
-        const int tap = p.taps[__builtin_amdgcn_readfirstlane(it)];
-        const int oy = (int)(signed char)(tap & 0xff), ox = (int)(signed char)((tap >> 8) & 0xff), wi = (tap >> 16) & 0xffff;
         const int c0 = ic * BK;
-        const unsigned wofs = (unsigned)(wi * p.Ci + c0) * 2u;
+        const bool second = FOLD && it == p.T;                // workgroup-uniform: the phase of the second operand
+        unsigned wofs;
+        if (!second) {
+            const int tap = p.taps[__builtin_amdgcn_readfirstlane(it)];
+            const int oy = (int)(signed char)(tap & 0xff), ox = (int)(signed char)((tap >> 8) & 0xff), wi = (tap >> 16) & 0xffff;
+            wofs = (unsigned)(wi * p.Ci + c0) * 2u;
 #pragma unroll
-        for (int j = 0; j < A_DMA; ++j) {
-            const int iy = a_y[j] + oy, ix = a_x[j] + ox;
-            const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            const unsigned off = (unsigned)((a_base[j] + iy * p.Wi + ix) * p.pix_stride + c0) * 2u + a_sw[j];
-            // a tap in the padding: an offset past the descriptor's size makes the DMA write zeros
-            dma16(a_rsrc, As + (wave * A_DMA + j) * 1024, ok ? off : PDT_OOB_OFFSET, 0u);
+            for (int j = 0; j < A_DMA; ++j) {
+                const int iy = a_y[j] + oy, ix = a_x[j] + ox;
+                const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                const unsigned off = (unsigned)((a_base[j] + iy * p.Wi + ix) * p.pix_stride + c0) * 2u + a_sw[j];
+                // a tap in the padding: an offset past the descriptor's size makes the DMA write zeros
+                dma16(a_rsrc, As + (wave * A_DMA + j) * 1024, ok ? off : PDT_OOB_OFFSET, 0u);
+            }
+        } else {
+            // (launcher: IS == 1 and the grid is the input image, so a_base + a_y * Wi + a_x is the GEMM row)
+            wofs = (unsigned)(p.T * p.Ci + c0) * 2u;
+#pragma unroll
+            for (int j = 0; j < A_DMA; ++j) {
+                const unsigned off = (unsigned)((a_base[j] + a_y[j] * p.Wi + a_x[j]) * p.pix_stride2 + c0) * 2u + a_sw[j];
+                dma16(a2_rsrc, As + (wave * A_DMA + j) * 1024, off, 0u);
+            }
         }
 #pragma unroll
         for (int j = 0; j < B_DMA; ++j) dma16(w_rsrc, Bs + (wave * B_DMA + j) * 1024, voff_b[j], wofs);
         ibuf = ibuf + 1 == R ? 0 : ibuf + 1;
-        if (++ic == kc) {
+        // (kc + (second ? kdiff : 0), not second ? kc2 : kc: a conditional between two variables captured by reference
+        // selects an ADDRESS, which keeps the closure in scratch memory and makes the cursor look divergent)
+        if (++ic == kc + (second ? kdiff : 0)) {
             ic = 0;
-            if (++it == p.T) {
+            if (++it == nphase) {
                 it = 0;
                 iv += gridDim.x;
                 if (iv < nwg) setup_issue_tile();
@@ -285,6 +324,12 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
 
     // ---- pipeline: R stages; at step s the DMA of step s+R-1 is issued (after the barrier that proves every
     // wave is done with the stage it overwrites) and the wait leaves the R-2 younger groups in flight
+    const bool has_bias = FOLD && p.bias != nullptr;
+    auto stage_bias = [&]() {                  // workgroup-uniform call sites; the barrier drains what is in flight
+        for (int i = tid; i < p.N; i += 256) bias_lds[i] = p.bias[i];
+        __syncthreads();
+    };
+    if (has_bias) stage_bias();
     setup_issue_tile();
     bool issuing = true;
 #pragma unroll
@@ -295,9 +340,13 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
         int m0, n0;
         tile_origin(v, m0, n0);               // the tile computed now
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int j = 0; j < NI; ++j) {
+            // accumulator register r of lane group fq: channel n0 + wn*WTN + j*16 + fq*4 + r
+            const f32x4 b0 = has_bias ? *reinterpret_cast<const f32x4*>(bias_lds + n0 + wn * WTN + j * 16 + fq * 4)
+                                      : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < MI; ++i) acc[i][j] = b0;
+        }
         for (int ks = 0; ks < nk; ++ks) {
             // This wave's share of the stage has landed: all but the (R-2)*G youngest operations are done, and
             // the operations issued after this step's group are at least the R-2 groups behind it (epilogue loads
@@ -317,7 +366,10 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
         // ---- epilogue, straight from the accumulators ------------------------------------------------------
         const int nb = n0 + wn * WTN + fq * 16;                       // first of this lane's 16 channels
         if (want_stats && stat_n0 != n0) {
-            if (stat_n0 >= 0) flush_stats(stat_n0);
+            if (stat_n0 >= 0) {
+                flush_stats(stat_n0);
+                if (has_bias) stage_bias();
+            }
             stat_n0 = n0;
             load_consts(nb);
         }
@@ -453,42 +505,64 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
     if (want_stats && stat_n0 >= 0) flush_stats(stat_n0);
 }
 
-template <int BN, int WM, int WN, int BK, int R, bool BSTAT>
+template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD = false>
 static int g1_resident_blocks() {
     static int cached = 0;
     if (cached > 0) return cached;
     int per_cu = 0, dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 512;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_dma_kernel<BN, WM, WN, BK, R, BSTAT>, 256, 0) != hipSuccess || per_cu <= 0)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_dma_kernel<BN, WM, WN, BK, R, BSTAT, FOLD>, 256, 0) != hipSuccess || per_cu <= 0)
         per_cu = 2;
     cached = per_cu * cus;
     return cached;
 }
 
-template <int BN, int WM, int WN, int BK, int R, bool BSTAT>
+template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD = false>
 static int g1_launch(const ConvDmaParams& p, hipStream_t s) {
     long long nwg = (long long)((p.M + 127) / 128) * (p.N / BN);
     if (nwg <= 0 || nwg > 0x7fffffffLL) return -2;
-    long long grid = g1_resident_blocks<BN, WM, WN, BK, R, BSTAT>();
+    long long grid = g1_resident_blocks<BN, WM, WN, BK, R, BSTAT, FOLD>();
     if (grid > nwg) grid = nwg;
     if (g_pdt_deterministic && grid > p.nrep) grid = p.nrep;      // one statistics row per workgroup
-    hipLaunchKernelGGL((conv_dma_kernel<BN, WM, WN, BK, R, BSTAT>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_dma_kernel<BN, WM, WN, BK, R, BSTAT, FOLD>), dim3((unsigned)grid), dim3(256), 0, s, p);
     return pdt_launch_status();
 }
 
 // tile: 0 = auto (3 when N is a multiple of 128, else 4); 3 = 128 x 128 with K slices of 64 and two stages, 4 = 128 x 64
 // with K slices of 64 and three stages (1 / 2 are old names of 3 / 4); 5 = 128 x 64 with K slices of 32 and four stages,
 // for operands with 32 channels per tap (the stem), never chosen automatically
-PDT_API int pdt_conv_dma(const void* in, const void* wgt, void* out, const void* addend, int addend_half,
-                         const void* mask_bits, float* stat_acc, const float* stat_shift, const void* bstat_y,
-                         const float* bstat_mean, const float* bstat_scale, const float* bstat_shift, long long M, int Hi,
-                         int Wi, int pix_stride, int Ci, int Hg, int Wg, int IS, int Ho, int Wo, int OS, int oy0, int ox0,
-                         int N, int wrow, int T, const signed char* offy, const signed char* offx,
-                         const unsigned short* widx, int tile, hipStream_t s) {
+// Persistent grid size (resident workgroups) of a kernel variant: tile 3 / 4, with or without the backward-sums epilogue
+// and the second-operand path (diagnostics).
+PDT_API int pdt_conv_dma_resident(int tile, int bstat, int fold) {
+    if (tile == 3) {
+        if (fold) return bstat ? g1_resident_blocks<128, 2, 2, 64, 2, true, true>() : g1_resident_blocks<128, 2, 2, 64, 2, false, true>();
+        return bstat ? g1_resident_blocks<128, 2, 2, 64, 2, true>() : g1_resident_blocks<128, 2, 2, 64, 2, false>();
+    }
+    if (fold) return bstat ? g1_resident_blocks<64, 4, 1, 64, 3, true, true>() : g1_resident_blocks<64, 4, 1, 64, 3, false, true>();
+    return bstat ? g1_resident_blocks<64, 4, 1, 64, 3, true>() : g1_resident_blocks<64, 4, 1, 64, 3, false>();
+}
+
+// in2 / Ci2 / pix_stride2 / bias: the optional second operand and accumulator start values (see the file header);
+// the weight rows then hold T*Ci columns for the taps followed by Ci2 columns for the second operand.
+PDT_API int pdt_conv_dma_ex(const void* in, const void* wgt, void* out, const void* addend, int addend_half,
+                            const void* mask_bits, float* stat_acc, const float* stat_shift, const void* bstat_y,
+                            const float* bstat_mean, const float* bstat_scale, const float* bstat_shift, long long M, int Hi,
+                            int Wi, int pix_stride, int Ci, int Hg, int Wg, int IS, int Ho, int Wo, int OS, int oy0, int ox0,
+                            int N, int wrow, int T, const signed char* offy, const signed char* offx,
+                            const unsigned short* widx, int tile, const void* in2, int Ci2, int pix_stride2,
+                            const float* bias, hipStream_t s) {
     if (T <= 0 || T > DMA_MAX_TAPS) return -3;
     if (M <= 0) return 0;
-    if (M >= 0x7fffffffLL || N < 64 || N % 64 != 0 || wrow < T * Ci) return -4;
+    if (!in2) Ci2 = 0;
+    if (M >= 0x7fffffffLL || N < 64 || N % 64 != 0 || wrow < T * Ci + Ci2) return -4;
+    if (in2) {
+        // the second operand is addressed by GEMM row: needs the plain 1x1 / stride 1 geometry
+        if (tile == 5 || T != 1 || offy[0] != 0 || offx[0] != 0 || IS != 1 || Hg != Hi || Wg != Wi) return -11;
+        if (Ci2 < 64 || Ci2 % 64 != 0 || pix_stride2 < Ci2 || pix_stride2 % 8 != 0) return -11;
+        if (M * (long long)pix_stride2 * 2 >= 0x7fff0000LL) return -7;
+    }
+    if (bias && N > DMA_MAX_BIAS) return -12;
     if (tile == 5) {
         // K slices of 32 over a gathered operand whose "pixels" may overlap (the stem reads 32 consecutive values of its
         // packed NHWC4 image per tap: pix_stride 4, Ci 32): every DMA source address must still be 16-byte aligned
@@ -514,6 +588,8 @@ PDT_API int pdt_conv_dma(const void* in, const void* wgt, void* out, const void*
     p.simple_out = (OS == 1 && oy0 == 0 && ox0 == 0 && Hg == Ho && Wg == Wo) ? 1 : 0;
     p.addend_half = (addend && addend_half) ? 1 : 0;
     p.nrep = pdt_nrep();
+    p.in2 = (const bf16*)in2; p.bias = bias; p.Ci2 = Ci2; p.pix_stride2 = in2 ? pix_stride2 : 0;
+    p.in2_bytes = in2 ? (unsigned)(M * (long long)pix_stride2 * 2) : 0u;
     {
         long long images = M / ((long long)Hg * Wg);
         long long in_b = images * Hi * Wi * pix_stride * 2, w_b = (long long)N * wrow * 2;
@@ -531,10 +607,26 @@ PDT_API int pdt_conv_dma(const void* in, const void* wgt, void* out, const void*
     if (tile == 1 || tile == 2) tile += 2;
     if (tile == 0) tile = (N % 128 == 0) ? 3 : 4;
     if (tile == 3 && N % 128 != 0) tile = 4;
+    if (in2 || bias) {
+        if (tile == 5) return -11;
+        if (tile == 3) return bs ? g1_launch<128, 2, 2, 64, 2, true, true>(p, s) : g1_launch<128, 2, 2, 64, 2, false, true>(p, s);
+        return bs ? g1_launch<64, 4, 1, 64, 3, true, true>(p, s) : g1_launch<64, 4, 1, 64, 3, false, true>(p, s);
+    }
     switch (tile) {
         case 3: return bs ? g1_launch<128, 2, 2, 64, 2, true>(p, s) : g1_launch<128, 2, 2, 64, 2, false>(p, s);
         case 4: return bs ? g1_launch<64, 4, 1, 64, 3, true>(p, s) : g1_launch<64, 4, 1, 64, 3, false>(p, s);
         case 5: return g1_launch<64, 4, 1, 32, 4, false>(p, s);       // 128 x 64, K slices of 32, ring of 4: the stem
         default: return -6;
     }
+}
+
+PDT_API int pdt_conv_dma(const void* in, const void* wgt, void* out, const void* addend, int addend_half,
+                         const void* mask_bits, float* stat_acc, const float* stat_shift, const void* bstat_y,
+                         const float* bstat_mean, const float* bstat_scale, const float* bstat_shift, long long M, int Hi,
+                         int Wi, int pix_stride, int Ci, int Hg, int Wg, int IS, int Ho, int Wo, int OS, int oy0, int ox0,
+                         int N, int wrow, int T, const signed char* offy, const signed char* offx,
+                         const unsigned short* widx, int tile, hipStream_t s) {
+    return pdt_conv_dma_ex(in, wgt, out, addend, addend_half, mask_bits, stat_acc, stat_shift, bstat_y, bstat_mean,
+                           bstat_scale, bstat_shift, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, wrow,
+                           T, offy, offx, widx, tile, nullptr, 0, 0, nullptr, s);
 }

@@ -57,6 +57,8 @@ struct WgradParams {
     long long rows_per_split;
     int step_b, step_y, step_x;        // BKP GEMM rows as (images, grid rows, grid columns): see row_advance
     int use_dma;                       // 128 x 128 tile: LDS-DMA staging (needs 16-byte aligned pixel rows)
+    const float* row_scale;            // [N] factor on output row n (null: 1): dW of a per-channel scaled dY without
+                                       // ever forming that tensor (folded BatchNorm backward, bn_fold.hip)
     // one 32-bit word per tap: offy (int8) | offx (int8) << 8 | widx (uint16) << 16.  Sub-dword
     // entries would be fetched with VECTOR loads (no scalar byte loads on gfx9), whose waits
     // drain the tile prefetches; a dword indexed by a wave-uniform tap is one s_load_dword.
@@ -283,8 +285,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
             for (int r = 0; r < 4; ++r) {
                 int n = co0 + wm * WTM + i * 16 + fq * 4 + r;
                 if (n < p.N && c < p.Ci) {
-                    if (p.ws) p.ws[(long long)split * p.slab + (long long)n * p.wrow + wofs + c] = acc[i][j][r];
-                    else atomicAdd(p.dw + (long long)n * p.wrow + wofs + c, acc[i][j][r]);
+                    const float v = p.row_scale ? acc[i][j][r] * p.row_scale[n] : acc[i][j][r];
+                    if (p.ws) p.ws[(long long)split * p.slab + (long long)n * p.wrow + wofs + c] = v;
+                    else atomicAdd(p.dw + (long long)n * p.wrow + wofs + c, v);
                 }
             }
         }
@@ -454,8 +457,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
             for (int r = 0; r < 4; ++r) {
                 int n = co0 + wm * WTM + i * 16 + fq * 4 + r;
                 if (n < p.N && c < p.Ci) {
-                    if (p.ws) p.ws[(long long)split * p.slab + (long long)n * p.wrow + wofs + c] = acc[i][j][r];
-                    else atomicAdd(p.dw + (long long)n * p.wrow + wofs + c, acc[i][j][r]);
+                    const float v = p.row_scale ? acc[i][j][r] * p.row_scale[n] : acc[i][j][r];
+                    if (p.ws) p.ws[(long long)split * p.slab + (long long)n * p.wrow + wofs + c] = v;
+                    else atomicAdd(p.dw + (long long)n * p.wrow + wofs + c, v);
                 }
             }
         }
@@ -625,8 +629,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(const WgradParams p)
                 for (int r = 0; r < 4; ++r) {
                     int n = co0 + wm * WTM + i * 16 + fq * 4 + r;
                     if (n < p.N && c < p.Ci) {
-                        if (p.ws) p.ws[(long long)split * p.slab + (long long)n * p.wrow + wofs + c] = acc[t][i][j][r];
-                        else atomicAdd(p.dw + (long long)n * p.wrow + wofs + c, acc[t][i][j][r]);
+                        const float v = p.row_scale ? acc[t][i][j][r] * p.row_scale[n] : acc[t][i][j][r];
+                        if (p.ws) p.ws[(long long)split * p.slab + (long long)n * p.wrow + wofs + c] = v;
+                        else atomicAdd(p.dw + (long long)n * p.wrow + wofs + c, v);
                     }
                 }
             }
@@ -718,10 +723,12 @@ static int launch_wgrad(WgradParams& p, hipStream_t s, int target_blocks, long l
 //       6 / 7 = 64x64 / 128x64 with three taps (one kernel row) per workgroup, Ci <= 64
 // ws / ws_bytes: workspace of the deterministic variant (NULL: float atomics).  It must stay untouched by other
 // streams until this launch has finished: one workspace per stream that issues weight gradients.
-PDT_API int pdt_conv_wgrad(const void* dy, const void* in, float* dw, long long M, int Hi, int Wi, int pix_stride,
-                           int Ci, int Hg, int Wg, int IS, int N, int ldy, int wrow, int T, const signed char* offy,
-                           const signed char* offx, const unsigned short* widx, int tile, int target_blocks,
-                           int atomic_budget_mb, float* ws, long long ws_bytes, hipStream_t s) {
+// row_scale: optional [N] factor applied to output row n before it is added to dw
+PDT_API int pdt_conv_wgrad_ex(const void* dy, const void* in, float* dw, long long M, int Hi, int Wi, int pix_stride,
+                              int Ci, int Hg, int Wg, int IS, int N, int ldy, int wrow, int T, const signed char* offy,
+                              const signed char* offx, const unsigned short* widx, int tile, int target_blocks,
+                              int atomic_budget_mb, float* ws, long long ws_bytes, const float* row_scale,
+                              hipStream_t s) {
     if (T <= 0 || T > MAX_TAPS) return -3;
     if (M <= 0) return 0;
     if (M >= 0x7fffffffLL) return -2;
@@ -729,6 +736,7 @@ PDT_API int pdt_conv_wgrad(const void* dy, const void* in, float* dw, long long 
     WgradParams p;
     p.dy = (const bf16*)dy; p.in = (const bf16*)in; p.dw = dw;
     p.ws = ws;
+    p.row_scale = row_scale;
     p.slab = (long long)N * wrow;
     long long ws_slabs = ws ? ws_bytes / (p.slab * 4) : 0;
     if (ws && ws_slabs < 1) return -8;
@@ -781,4 +789,12 @@ PDT_API int pdt_conv_wgrad(const void* dy, const void* in, float* dw, long long 
         case 7: return launch_wgrad_taps<128, 64, 2, 2, 3>(p, s, target_blocks, ws_slabs);
         default: return -6;
     }
+}
+
+PDT_API int pdt_conv_wgrad(const void* dy, const void* in, float* dw, long long M, int Hi, int Wi, int pix_stride,
+                           int Ci, int Hg, int Wg, int IS, int N, int ldy, int wrow, int T, const signed char* offy,
+                           const signed char* offx, const unsigned short* widx, int tile, int target_blocks,
+                           int atomic_budget_mb, float* ws, long long ws_bytes, hipStream_t s) {
+    return pdt_conv_wgrad_ex(dy, in, dw, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow, T, offy, offx, widx, tile,
+                             target_blocks, atomic_budget_mb, ws, ws_bytes, nullptr, s);
 }

@@ -80,6 +80,12 @@ _sig("pdt_conv_igemm_bstats", _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _v
 _sig("pdt_conv_dma", _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
      _i, _i, _i, _vp, _vp, _vp, _i, _vp)
 _sig("pdt_conv_wgrad", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _ll, _vp)
+_sig("pdt_conv_wgrad_ex", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _ll,
+     _vp, _vp)
+_sig("pdt_conv_dma_ex", _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+     _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp)
+_sig("pdt_bnfold_prepare", _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp)
+_sig("pdt_bnfold_wgrad", _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _vp)
 _sig("pdt_set_deterministic", _i)
 _sig("pdt_accumulator_rows")
 
@@ -340,7 +346,7 @@ def _igemm(inp, wgt, out, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0
 
 
 def _wgrad(dy, inp, dw, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow, taps: _Taps, tile: int = 0,
-           target_blocks: int = 0, atomic_budget_mb: int = 0) -> None:
+           target_blocks: int = 0, atomic_budget_mb: int = 0, row_scale=None) -> None:
     parts = _batch_parts(inp.shape[0], max(inp.numel(), dy.numel()) * 2)
     if parts is not None:
         B = inp.shape[0]
@@ -348,13 +354,13 @@ def _wgrad(dy, inp, dw, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow, tap
             raise ValueError("conv_wgrad: cannot split this launch over the batch")
         for b0, b1 in parts:
             _wgrad(dy[b0:b1], inp[b0:b1], dw, (M // B) * (b1 - b0), Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow,
-                   taps, tile=tile, target_blocks=target_blocks, atomic_budget_mb=atomic_budget_mb)
+                   taps, tile=tile, target_blocks=target_blocks, atomic_budget_mb=atomic_budget_mb, row_scale=row_scale)
         return
     stream = _stream()
     ws, ws_bytes = _wgrad_workspace(dw.device, stream)
-    rc = _lib.pdt_conv_wgrad(_p(dy), _p(inp), _p(dw), M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow, taps.T,
-                             taps.offy, taps.offx, taps.widx, tile, target_blocks, atomic_budget_mb, ws, ws_bytes,
-                             stream)
+    rc = _lib.pdt_conv_wgrad_ex(_p(dy), _p(inp), _p(dw), M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow, taps.T,
+                                taps.offy, taps.offx, taps.widx, tile, target_blocks, atomic_budget_mb, ws, ws_bytes,
+                                _p(row_scale), stream)
     _check(rc, "pdt_conv_wgrad")
 
 
@@ -846,6 +852,107 @@ def bn_bwd_elemt(g, y, mean, invstd, scale, shift, sums, inv_count: float, mask_
     _check(rc, "pdt_bn_bwd_elemt")
     return dx
 
+
+
+# --------------------------------------------------------------------------- folded BatchNorm backward
+bn_fold = True               # bn_fold_prepare / conv_dgrad_folded / conv_wgrad_folded (csrc/bn_fold.hip)
+BN_FOLD_MAX_C = 512          # accumulator start values of the data-gradient kernel live in LDS
+
+
+class BnFold:
+    """What :func:`bn_fold_prepare` hands to the two folded gradient products of one layer."""
+
+    __slots__ = ("wfold", "bias", "coef", "C", "N")
+
+    def __init__(self, wfold, bias, coef, C: int, N: int) -> None:
+        self.wfold, self.bias, self.coef, self.C, self.N = wfold, bias, coef, C, N
+
+    def tensors(self):
+        return self.wfold, self.bias, self.coef
+
+
+def bn_fold_prepare(sums, scale, invstd, mean, inv_count: float, w: torch.Tensor, wt: torch.Tensor) -> BnFold:
+    """Fold the backward of the BatchNorm behind a 1x1 / stride 1 convolution ``y = a . w^T`` into that
+    convolution's two gradient products (math: :func:`..ref.bn_fold_prepare`).  ``w``: ``[N, 1, 1, C]``,
+    ``wt``: its data-gradient copy ``[C, 1, 1, N]``; ``sums``: the reduced ``[2, N]`` backward sums."""
+    wt = _bf16c(wt, "bn_fold_prepare wt")
+    C, N = wt.shape[0], wt.shape[-1]
+    if wt.numel() != C * N or C % 64 or N % 64 or C > BN_FOLD_MAX_C:
+        raise ValueError(f"bn_fold_prepare: needs a 1x1 filter with channel counts in multiples of 64 and at most "
+                         f"{BN_FOLD_MAX_C} input channels, got {tuple(wt.shape)}")
+    dev = wt.device
+    wfold = torch.empty(C, N + C, dtype=torch.bfloat16, device=dev)
+    bias = torch.empty(C, dtype=torch.float32, device=dev)
+    coef = torch.empty(3, N, dtype=torch.float32, device=dev)
+    rc = _lib.pdt_bnfold_prepare(_p(_f32c(sums, "bn_fold_prepare sums")), _p(scale), _p(invstd), _p(mean), inv_count,
+                                 _p(wt), _p(wfold), _p(bias), _p(coef), C, N, _stream())
+    _check(rc, "pdt_bnfold_prepare")
+    return BnFold(wfold, bias, coef, C, N)
+
+
+def conv_dgrad_folded(g: torch.Tensor, a_in: torch.Tensor, fold: BnFold, bwd_stats=None,
+                      out: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
+    """Data gradient of ``conv1x1 -> BatchNorm`` w.r.t. the convolution input ``a_in`` from ``g``, the gradient
+    w.r.t. the BatchNorm OUTPUT: ``g . (A o w) + a_in . S + bias`` in one kernel (``bwd_stats`` as in
+    :func:`conv_dgrad`)."""
+    g = _bf16c(g, "conv_dgrad_folded g")
+    a_in = _bf16c(a_in, "conv_dgrad_folded a_in")
+    B, H, W, N = g.shape
+    C = a_in.shape[-1]
+    if tuple(a_in.shape[:3]) != (B, H, W) or (C, N) != (fold.C, fold.N):
+        raise ValueError("conv_dgrad_folded: tensor shapes do not belong to the folded layer")
+    dx = _out_like(out, (B, H, W, C), g.device, "conv_dgrad_folded")
+    acc = by = bmean = bscale = bshift = None
+    if bwd_stats is not None:
+        by, bmean, bscale, bshift, bmode = bwd_stats
+        by = _bf16c(by, "conv_dgrad_folded bwd_stats y")
+        if tuple(by.shape) != (B, H, W, C) or bmode not in (MASK_NONE, MASK_RECOMPUTE):
+            raise ValueError("conv_dgrad_folded: bwd_stats tensor/mode does not match the gradient being produced")
+        if bmode != MASK_RECOMPUTE:
+            bscale = bshift = None
+        acc = _accumulator(g.device, C, "bwd")
+    taps = _one_tap()
+    parts = _batch_parts(B, g.numel() * 2) or [(0, B)]
+    for b0, b1 in parts:
+        M = (b1 - b0) * H * W
+        rc = _lib.pdt_conv_dma_ex(_p(g[b0:b1]), _p(fold.wfold), _p(dx[b0:b1]), None, 0, None, _p(acc), None,
+                                  _p(by[b0:b1]) if by is not None else None, _p(bmean), _p(bscale), _p(bshift), M, H, W, N,
+                                  N, H, W, 1, H, W, 1, 0, 0, C, N + C, 1, taps.offy, taps.offx, taps.widx, tile,
+                                  _p(a_in[b0:b1]), C, C, _p(fold.bias), _stream())
+        _check(rc, "pdt_conv_dma_ex")
+    return dx
+
+
+def conv_wgrad_folded(a_in: torch.Tensor, g: torch.Tensor, fold: BnFold, w: torch.Tensor, dw: torch.Tensor) -> None:
+    """``dw += (A o g + B o y + K)^T . a_in`` without the tensor in parentheses and without ``y``: the scaled
+    product ``A o (g^T a)``, the Gram matrix ``a^T a`` (an ordinary weight-gradient launch with ``a`` on both
+    sides), the column means of ``a``, and the small correction kernel."""
+    if _ABLATE_WGRAD:
+        return
+    a_in = _bf16c(a_in, "conv_wgrad_folded a_in")
+    g = _bf16c(g, "conv_wgrad_folded g")
+    w = _bf16c(w, "conv_wgrad_folded w")
+    _f32c(dw, "conv_wgrad_folded dw")
+    B, H, W, C = a_in.shape
+    N = g.shape[-1]
+    if (C, N) != (fold.C, fold.N) or w.numel() != N * C or dw.numel() != N * C:
+        raise ValueError("conv_wgrad_folded: tensor shapes do not belong to the folded layer")
+    rows = B * H * W
+    dev = a_in.device
+    taps = _one_tap()
+    # column means of a
+    acc = _accumulator(dev, C, "fold")
+    _check(_lib.pdt_bn_stats_accum(_p(a_in), None, _p(acc), rows, C, _stream()), "pdt_bn_stats_accum")
+    mom = torch.empty(2, C, dtype=torch.float32, device=dev)
+    _check(_lib.pdt_bn_moments(_p(acc), _p(mom), C, 1.0 / rows, _stream()), "pdt_bn_moments")
+    # G = a^T a
+    gram = torch.empty(C, C, dtype=torch.float32, device=dev)
+    _check(_lib.pdt_zero_f32(_p(gram), C * C, _stream()), "pdt_zero_f32")
+    _wgrad(a_in, a_in, gram, rows, H, W, C, C, H, W, 1, C, C, C, taps)
+    # A o (g^T a) straight into the gradient buffer, then the correction
+    _wgrad(g, a_in, dw, rows, H, W, C, C, H, W, 1, N, N, C, taps, row_scale=fold.coef[0])
+    rc = _lib.pdt_bnfold_wgrad(_p(dw), _p(w), _p(gram), _p(mom), float(rows), _p(fold.coef), C, N, _stream())
+    _check(rc, "pdt_bnfold_wgrad")
 
 # --------------------------------------------------------------------------- pooling
 def maxpool_fwd(x):

@@ -285,6 +285,74 @@ def bn_bwd_elemt(g, y, mean, invstd, scale, shift, sums, inv_count: float, mask_
     return dx.to(y.dtype)
 
 
+
+# ---------------------------------------------------------------------------- folded BatchNorm backward
+bn_fold = True
+BN_FOLD_MAX_C = 512
+
+
+class BnFold:
+    __slots__ = ("wfold", "bias", "coef", "C", "N")
+
+    def __init__(self, wfold, bias, coef, C: int, N: int) -> None:
+        self.wfold, self.bias, self.coef, self.C, self.N = wfold, bias, coef, C, N
+
+    def tensors(self):
+        return self.wfold, self.bias, self.coef
+
+
+def bn_fold_prepare(sums, scale, invstd, mean, inv_count: float, w: torch.Tensor, wt=None) -> BnFold:
+    """BatchNorm backward folded into the 1x1 / stride 1 convolution ``y = a . w^T`` in front of it.
+
+    With the reduced sums of :func:`bn_bwd_reduce`, the gradient w.r.t. the conv output is, per channel n,
+    ``d = A g + B y + K`` with ``A = scale``, ``B = -scale * invstd * sums[1] * inv_count``,
+    ``K = -scale * sums[0] * inv_count - B * mean`` (:func:`bn_bwd_elemt` written out).  Because ``y`` is a
+    product with ``w`` itself, both gradient products of the convolution can be formed from ``g`` and ``a``
+    alone -- neither ``d`` nor ``y`` is touched:
+
+    * data gradient ``d . w = g . (A o w) + a . S + bias`` with ``S = w^T diag(B) w`` (``[C, C]``) and
+      ``bias = K . w``: :func:`conv_dgrad_folded`;
+    * weight gradient ``d^T a = A o (g^T a) + B o (w . (a^T a)) + K (x) colsum(a)``: :func:`conv_wgrad_folded`.
+
+    Returns the folded data-gradient weights ``[C, N + C]`` (``[(A o w)^T | S]``, compute dtype), ``bias [C]``
+    and ``coef = [A, B, K]`` (``[3, N]``).  ``y`` here is the exact product; a backend's stored ``y`` is that
+    product rounded to the compute dtype, so results agree with :func:`bn_bwd_elemt` + :func:`conv_dgrad` /
+    :func:`conv_wgrad` up to that rounding (and are free of the rounding of ``d``).
+    """
+    N, C = w.shape[0], w.shape[-1]
+    w2 = w.reshape(N, C).float()
+    k0, k1 = sums[0] * inv_count, sums[1] * inv_count
+    A = scale.float()
+    Bc = -A * k1 * invstd
+    K = -A * k0 - Bc * mean
+    S = w2.t() @ (Bc[:, None] * w2)
+    wfold = torch.cat([(w2 * A[:, None]).t(), S], dim=1).to(w.dtype).contiguous()
+    return BnFold(wfold, K @ w2, torch.stack([A, Bc, K]).contiguous(), C, N)
+
+
+def conv_dgrad_folded(g: torch.Tensor, a_in: torch.Tensor, fold: BnFold, bwd_stats=None,
+                      out: Optional[torch.Tensor] = None, **_) -> torch.Tensor:
+    """``g . (A o w) + a_in . S + bias`` (see :func:`bn_fold_prepare`); ``bwd_stats`` is a fused backend's
+    business (ignored here like in :func:`conv_dgrad`)."""
+    N, C = fold.N, fold.C
+    wf = fold.wfold.float()
+    dx = g.float().reshape(-1, N) @ wf[:, :N].t() + a_in.float().reshape(-1, C) @ wf[:, N:].t() + fold.bias
+    dx = dx.reshape(a_in.shape).to(g.dtype)
+    if out is not None:
+        out.copy_(dx)
+        return out
+    return dx
+
+
+def conv_wgrad_folded(a_in: torch.Tensor, g: torch.Tensor, fold: BnFold, w: torch.Tensor, dw: torch.Tensor) -> None:
+    """``dw += A o (g^T a) + B o (w . (a^T a)) + K (x) colsum(a)`` (see :func:`bn_fold_prepare`)."""
+    N, C = fold.N, fold.C
+    a2, g2 = a_in.float().reshape(-1, C), g.float().reshape(-1, N)
+    A, Bc, K = fold.coef[0], fold.coef[1], fold.coef[2]
+    gram = a2.t() @ a2
+    upd = A[:, None] * (g2.t() @ a2) + Bc[:, None] * (w.reshape(N, C).float() @ gram) + K[:, None] * a2.sum(0)[None, :]
+    dw.add_(upd.reshape(dw.shape))
+
 # ---------------------------------------------------------------------------- pooling
 def maxpool_fwd(x: torch.Tensor):
     """3x3 / stride 2 / pad 1 max pooling; returns ``(out, idx)`` with an opaque index tensor."""

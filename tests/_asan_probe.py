@@ -38,6 +38,21 @@ def on_gpu(hip) -> None:
         assert ((dw - dwr).norm() / dwr.norm()).item() < 5e-3
         m = hip.bn_stats(y)
         assert torch.allclose(m, ref.bn_stats(y), rtol=2e-3, atol=2e-3)
+        # folded BatchNorm backward: prepare, data gradient with a second operand, scaled weight gradient + correction
+        a = torch.relu(torch.randn(4, 14, 14, 64, device=dev)).to(torch.bfloat16)
+        w1 = (torch.randn(256, 1, 1, 64, device=dev) * 0.1).to(torch.bfloat16)
+        wt = torch.empty(64, 1, 1, 256, dtype=torch.bfloat16, device=dev)
+        hip.transpose_weights(w1, wt)
+        g = (torch.randn(4, 14, 14, 256, device=dev) * 0.1).to(torch.bfloat16)
+        sums, vec = torch.randn(2, 256, device=dev), torch.rand(256, device=dev) + 0.5
+        fold = hip.bn_fold_prepare(sums, vec, vec, vec, 1.0 / 784, w1, wt)
+        dx = hip.conv_dgrad_folded(g, a, fold)
+        dxr = ref.conv_dgrad_folded(g, a, fold)
+        assert ((dx.float() - dxr.float()).norm() / dxr.float().norm()).item() < 2e-2
+        dw1, dw1r = torch.zeros(256, 1, 1, 64, device=dev), torch.zeros(256, 1, 1, 64, device=dev)
+        hip.conv_wgrad_folded(a, g, fold, w1, dw1)
+        ref.conv_wgrad_folded(a, g, fold, w1, dw1r)
+        assert ((dw1 - dw1r).norm() / dw1r.norm()).item() < 5e-3
     hip.set_deterministic(False)
     torch.cuda.synchronize()
 
