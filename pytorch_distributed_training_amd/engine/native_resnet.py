@@ -194,6 +194,10 @@ class NativeResNet:
         # gradients) and loses on the 7x7 stage (103 MB).
         self._bn_fold_min_bytes = int(float(os.environ.get("PDT_BN_FOLD_MIN_MB", "150")) * 2 ** 20) \
             if self.device.type == "cuda" else 0
+        # Folded units take their backward sum s1 from the (unscaled) weight-gradient product, so the kernel that
+        # produces their incoming gradient only adds up the gradient itself and reads no BatchNorm input for them;
+        # with that, a stride-1 projection shortcut is folded as well (PDT_BN_FOLD_PRODUCT=0: sums as before).
+        self._bn_fold_product = self._bn_fold and os.environ.get("PDT_BN_FOLD_PRODUCT", "1") == "1"
         # Step replay (see .graphs): the second step of a batch signature is recorded, later ones
         # replay the record.  "list": a command list of the backend's own launches (default);
         # "graph": HIP graphs separated by host actions.  PDT_HIP_GRAPHS: 0 = off, 1 = on,
@@ -454,6 +458,11 @@ class NativeResNet:
                                      P.grad(f"{u.bn}.weight"), P.grad(f"{u.bn}.bias"), comm=self._xgmi, **kw)
         sums = ops.bn_bwd_reduce(g, ctx.y, ctx.mean, ctx.invstd, ctx.scale, ctx.shift, mask_src, mask_mode,
                                  P.grad(f"{u.bn}.weight"), P.grad(f"{u.bn}.bias"), **kw)
+        self._allreduce_bwd_sums(sums)
+        return sums
+
+    def _allreduce_bwd_sums(self, sums: torch.Tensor) -> None:
+        """SyncBN: sum the local ``[2, C]`` backward sums over the ranks, in place."""
         if self.sync_bn:
             # The all-reduce sits on the critical path (dgrad needs its result).  With
             # ``syncbn_overlap`` the weight gradient of the unit processed just before, which is
@@ -470,7 +479,6 @@ class NativeResNet:
                 self._host(lambda: pending.pop().wait())
             else:
                 self._host(lambda: coll.all_reduce(sums, group=group))
-        return sums
 
     def _wgrad(self, fn) -> None:
         """Run a weight-gradient closure now, or (SyncBN) hold it back until the next statistics
@@ -727,30 +735,31 @@ class NativeResNet:
             return True
         return u.cin % 64 == 0 and u.cout % 64 == 0 and u.cin <= self.ops.BN_FOLD_MAX_C
 
-    def _folded_wgrad_fn(self, u: ConvBNSpec, x: torch.Tensor, g: torch.Tensor, fold):
+    def _folded_wgrad_fn(self, u: ConvBNSpec, x: torch.Tensor, g: torch.Tensor, fold, prod=None):
         """Like :meth:`_conv_wgrad_fn`, for a unit whose BatchNorm backward is folded (``g`` is the gradient
-        w.r.t. the BatchNorm output)."""
+        w.r.t. the BatchNorm output; ``prod``: the unscaled product ``g^T x`` when it exists already)."""
         P, ops, red = self.params, self.ops, self.reducer
         key = f"{u.conv}.weight"
+        kw = {"prod": prod} if prod is not None else {}
 
         def run() -> None:
             end = P.end_offset(key)
             ws = self._wgrad_stream
             if ws is None:
-                ops.conv_wgrad_folded(x, g, fold, P.compute(key), P.grad(key))
+                ops.conv_wgrad_folded(x, g, fold, P.compute(key), P.grad(key), **kw)
             else:
                 cur = torch.cuda.current_stream(self.device).cuda_stream
                 ops.stream_wait_stream(ws.cuda_stream, cur, self._fork_event)
                 with torch.cuda.stream(ws):
-                    ops.conv_wgrad_folded(x, g, fold, P.compute(key), P.grad(key))
-                self._wgrad_keep.append((x, g, *fold.tensors()))   # must outlive the side-stream kernels
+                    ops.conv_wgrad_folded(x, g, fold, P.compute(key), P.grad(key), **kw)
+                self._wgrad_keep.append((x, g, prod, *fold.tensors()))   # must outlive the side-stream kernels
                 if red.completes_bucket(end) and not self._reducer_waits_wgrad:
                     self._join_wgrad()
             self._mark_ready(end)
         return run
 
-    def _folded_tail_backward(self, u: ConvBNSpec, prev_u: ConvBNSpec, ctx: _UnitCtx, g: torch.Tensor,
-                              prereduced: bool) -> torch.Tensor:
+    def _folded_tail_backward(self, u: ConvBNSpec, prev_u: Optional[ConvBNSpec], ctx: _UnitCtx, g: torch.Tensor,
+                              prereduced: bool, s0: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Backward of a bottleneck block's last unit (1x1 convolution + BatchNorm) WITHOUT the gradient w.r.t.
         the convolution output: that tensor has 4x the channels of the unit's input, and the elementwise pass
         that writes it plus the two kernels that read it back are a quarter of the block's backward traffic.
@@ -758,12 +767,23 @@ class NativeResNet:
         small per-step matrices (``ops.bn_fold_prepare``) and both gradient products read ``g`` and the unit's
         INPUT instead (``ops.conv_dgrad_folded`` / ``ops.conv_wgrad_folded``)."""
         P, ops = self.params, self.ops
-        sums = self._bn_backward_sums(u, ctx, g, None, MASK_NONE, prereduced)
         key = f"{u.conv}.weight"
+        prod = None
+        if s0 is None:
+            sums = self._bn_backward_sums(u, ctx, g, None, MASK_NONE, prereduced)
+        else:
+            # ``s0 = sum g`` came with g; ``sum g * xhat`` follows from the product g^T x, which the weight gradient
+            # needs anyway: formed here, on the critical stream, scaled and added by the correction kernel later
+            prod = ops.zeros_f32(P.grad(key).shape, self.device)
+            ops.conv_wgrad(ctx.x_in, g, 1, 1, 1, 0, prod)
+            sums = ops.bn_fold_sums(prod, P.compute(key), s0, ctx.mean, ctx.invstd, P.grad(f"{u.bn}.weight"),
+                                    P.grad(f"{u.bn}.bias"))
+            self._allreduce_bwd_sums(sums)
         fold = ops.bn_fold_prepare(sums, ctx.scale, ctx.invstd, ctx.mean, 1.0 / ctx.count, P.compute(key),
                                    self._wt_view(key))
-        self._wgrad(self._folded_wgrad_fn(u, ctx.x_in, g, fold))
-        return ops.conv_dgrad_folded(g, ctx.x_in, fold, **(self._bstats(prev_u, MASK_RECOMPUTE) or {}))
+        self._wgrad(self._folded_wgrad_fn(u, ctx.x_in, g, fold, prod))
+        return ops.conv_dgrad_folded(g, ctx.x_in, fold,
+                                     **((self._bstats(prev_u, MASK_RECOMPUTE) or {}) if prev_u is not None else {}))
 
     def _sliced_tail_backward(self, u: ConvBNSpec, prev_u: ConvBNSpec, ctx: _UnitCtx, g: torch.Tensor,
                               prereduced: bool) -> torch.Tensor:
@@ -794,8 +814,8 @@ class NativeResNet:
                            u.stride, u.pad, out=dx[sl], **kw)
         return dx
 
-    def _block_backward(self, b: BlockSpec, g: torch.Tensor, g_prereduced: bool = False,
-                        prev_last: Optional[ConvBNSpec] = None) -> Tuple[torch.Tensor, bool]:
+    def _block_backward(self, b: BlockSpec, g: torch.Tensor, g_prereduced=False,
+                        prev_last: Optional[ConvBNSpec] = None) -> Tuple[torch.Tensor, object]:
         """``g``: gradient w.r.t. the block's pre-ReLU sum, i.e. ALREADY multiplied by the mask of
         the block's output ReLU (the producer of ``g`` fuses that).  Returns the gradient w.r.t.
         the block input, likewise already masked by the input tensor's own ReLU.
@@ -804,18 +824,23 @@ class NativeResNet:
         ``prev_last``'s BatchNorm (what the caller passes as the next ``g_prereduced``).
 
         ``g_prereduced``: the kernel that produced ``g`` also accumulated the backward sums of this
-        block's last BatchNorm.  ``prev_last``: the last unit of the block that produced this
-        block's input -- the final data-gradient kernel here does the same for it."""
+        block's last BatchNorm (True), or only the per-channel sums of ``g`` itself (``"s0"``: the last unit is
+        folded and takes the rest from its weight-gradient product).  ``prev_last``: the last unit of the block
+        that produced this block's input -- the final data-gradient kernel here does the same for it."""
         P, ops, red = self.params, self.ops, self.reducer
         last = len(b.units) - 1
         x_block = self._ctx[b.units[0].bn].x_in
         cur = g
         dy_first = None
+        s0 = None
+        if g_prereduced == "s0":
+            s0 = ops.grad_sums(g.shape[-1], self.device)[0]
+            g_prereduced = False
         for i in range(last, -1, -1):
             u = b.units[i]
             ctx = self._ctx.pop(u.bn)
             if i == last and i > 0 and self._can_fold(u, ctx.y):
-                cur = self._folded_tail_backward(u, b.units[i - 1], ctx, cur, g_prereduced)
+                cur = self._folded_tail_backward(u, b.units[i - 1], ctx, cur, g_prereduced, s0)
                 continue
             if i == last and i > 0 and self._can_slice_bwd() and self._n_slices(ctx.y) > 1:
                 cur = self._sliced_tail_backward(u, b.units[i - 1], ctx, cur, g_prereduced)
@@ -838,11 +863,18 @@ class NativeResNet:
         if b.downsample is not None:
             d = b.downsample
             ctx = self._ctx.pop(d.bn)
-            dyd = self._bn_backward(d, ctx, g, None, MASK_NONE)
-            keyd = f"{d.conv}.weight"
-            self._wgrad(self._conv_wgrad_fn(d, x_block, dyd))
             Bx, Hx, Wx, Cx = x_block.shape
-            if self._half_addend and d.ksize == 1 and d.stride == 2 and d.pad == 0 and Hx % 2 == 0 and Wx % 2 == 0:
+            if s0 is not None and self._can_fold(d, ctx.y):
+                # (same g as the block's last BatchNorm: the same s0)
+                other = self._folded_tail_backward(d, None, ctx, g, False, s0)
+                dyd = None
+            else:
+                dyd = self._bn_backward(d, ctx, g, None, MASK_NONE)
+                keyd = f"{d.conv}.weight"
+                self._wgrad(self._conv_wgrad_fn(d, x_block, dyd))
+            if dyd is None:
+                pass
+            elif self._half_addend and d.ksize == 1 and d.stride == 2 and d.pad == 0 and Hx % 2 == 0 and Wx % 2 == 0:
                 # A stride-2 1x1 shortcut touches the even input pixels only: its data gradient is
                 # kept at half resolution (a plain 1x1 product) and the kernel below adds it at
                 # those pixels, instead of writing and re-reading a tensor that is 3/4 zeros.
@@ -858,12 +890,16 @@ class NativeResNet:
         # where a zero means the whole pooling window was zero): apply its ReLU backward here.
         bits = getattr(x_block, "_pdt_relu_bits", None)
         mkw = {"relu_bits": bits} if bits is not None else {"relu_mask": x_block}
-        # the fused backward sums of the previous block's last BatchNorm need the packed mask
-        skw = (self._bstats(prev_last, MASK_NONE) or {}) if (bits is not None or not self._relu_bits_only) else {}
+        if prev_last is not None and self._bn_fold_product and self._can_fold(prev_last, self._ctx[prev_last.bn].y):
+            skw, pre = {"out_sums": True}, "s0"      # that unit is folded: all it wants with g is sum g
+        else:
+            # the fused backward sums of the previous block's last BatchNorm need the packed mask
+            skw = (self._bstats(prev_last, MASK_NONE) or {}) if (bits is not None or not self._relu_bits_only) else {}
+            pre = bool(skw)
         g_in = ops.conv_dgrad(dy_first, P.compute(key0), self._wt_view(key0), tuple(x_block.shape),
                               u0.ksize, u0.ksize, u0.stride, u0.pad, addend=other, **mkw, **skw,
                               **({"addend_half": True} if half else {}))
-        return g_in, bool(skw)
+        return g_in, pre
 
     def backward(self, dlogits: torch.Tensor) -> None:
         """Back-propagate ``dlogits``; gradients accumulate into the flat gradient buffer."""

@@ -19,7 +19,9 @@
 // small kernels around them:
 //
 //   * bnfold_prepare:  coefficients, the folded weight rows [A o Wt | S] in the data-gradient layout, and bias;
-//   * bnfold_wgrad:    dW += B o (W . G) + K (x) colsum(a).
+//   * bnfold_wgrad:    dW += B o (W . G) + K (x) colsum(a)   (+ A o T when the product T = g^T a was kept unscaled);
+//   * bnfold_sums:     the backward sum s1 = sum g * xhat from T as well: sum_m g y = sum_c W[n][c] T[n][c], so the
+//                      kernel that produces g only has to add up g itself (s0) and does not read y either.
 //
 // Both multiply on the matrix cores (v_mfma_f32_32x32x16_bf16, operands straight from global memory: the matrices
 // are a few hundred rows, launch latency is what counts).  G holds sums over ~10^6 pixels, so its bf16 operand is
@@ -153,7 +155,8 @@ PDT_API int pdt_bnfold_prepare(const float* sums, const float* scale, const floa
 __global__ __launch_bounds__(256) void bnfold_wgrad_kernel(float* __restrict__ dw, const bf16* __restrict__ w,
                                                             const float* __restrict__ gram,
                                                             const float* __restrict__ amean, float rows,
-                                                            const float* __restrict__ coef, int C, int N) {
+                                                            const float* __restrict__ coef,
+                                                            const float* __restrict__ prod, int C, int N) {
     __shared__ float red[4 * 16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_c = C / 32;
@@ -188,14 +191,55 @@ __global__ __launch_bounds__(256) void bnfold_wgrad_kernel(float* __restrict__ d
         int row, col;
         tile_rc(tid + q * 256, row, col);
         const int n = 32 * bi + row, c = 32 * bj + col;
-        dw[(size_t)n * C + c] += coef[N + n] * out[q] + coef[2 * N + n] * (rows * amean[c]);
+        float v = coef[N + n] * out[q] + coef[2 * N + n] * (rows * amean[c]);
+        if (prod) v += coef[n] * prod[(size_t)n * C + c];
+        dw[(size_t)n * C + c] += v;
     }
 }
 
+// prod: the unscaled product T = g^T a [N][C] (then dw also receives A o T), or null when a scaled weight-gradient
+// launch has already added it
 PDT_API int pdt_bnfold_wgrad(float* dw, const void* w, const float* gram, const float* amean, float rows,
-                             const float* coef, int C, int N, hipStream_t s) {
+                             const float* coef, const float* prod, int C, int N, hipStream_t s) {
     if (C < 64 || C % 64 != 0 || N < 32 || N % 32 != 0) return -4;
     hipLaunchKernelGGL(bnfold_wgrad_kernel, dim3((N / 32) * (C / 32)), dim3(256), 0, s, dw, (const bf16*)w, gram, amean,
-                       rows, coef, C, N);
+                       rows, coef, prod, C, N);
+    return pdt_launch_status();
+}
+
+// sums[0][n] = s0[n];  sums[1][n] = invstd[n] (sum_c W[n][c] T[n][c] - mean[n] s0[n]);  dbeta += s0, dgamma += s1.
+// One wave per channel n.
+__global__ __launch_bounds__(256) void bnfold_sums_kernel(const float* __restrict__ prod, const bf16* __restrict__ w,
+                                                           const float* __restrict__ s0, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, float* __restrict__ sums,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
+                                                           int N) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float part = 0.f;
+    for (int c = lane * 8; c < C; c += 64 * 8) {
+        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + (size_t)n * C + c);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(prod + (size_t)n * C + c);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(prod + (size_t)n * C + c + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part += bf2f(wv[k]) * t0[k] + bf2f(wv[4 + k]) * t1[k];
+    }
+    part = wave_sum(part);
+    if (lane == 0) {
+        const float a = s0[n];
+        const float b = invstd[n] * (part - mean[n] * a);
+        sums[n] = a;
+        sums[N + n] = b;
+        if (dbeta) dbeta[n] += a;
+        if (dgamma) dgamma[n] += b;
+    }
+}
+
+PDT_API int pdt_bnfold_sums(const float* prod, const void* w, const float* s0, const float* mean, const float* invstd,
+                            float* sums, float* dgamma, float* dbeta, int C, int N, hipStream_t s) {
+    if (C < 8 || C % 8 != 0 || N < 1) return -4;
+    hipLaunchKernelGGL(bnfold_sums_kernel, dim3((N + 3) / 4), dim3(256), 0, s, prod, (const bf16*)w, s0, mean, invstd, sums,
+                       dgamma, dbeta, C, N);
     return pdt_launch_status();
 }

@@ -85,7 +85,8 @@ _sig("pdt_conv_wgrad_ex", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i
 _sig("pdt_conv_dma_ex", _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
      _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp)
 _sig("pdt_bnfold_prepare", _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp)
-_sig("pdt_bnfold_wgrad", _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _vp)
+_sig("pdt_bnfold_wgrad", _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp)
+_sig("pdt_bnfold_sums", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp)
 _sig("pdt_set_deterministic", _i)
 _sig("pdt_accumulator_rows")
 
@@ -587,11 +588,12 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pa
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R: int, S: int, stride: int, pad: int,
                addend: Optional[torch.Tensor] = None, relu_mask: Optional[torch.Tensor] = None, tile: int = 0,
                bwd_stats=None, out: Optional[torch.Tensor] = None, relu_bits: Optional[torch.Tensor] = None,
-               addend_half: bool = False):
+               addend_half: bool = False, out_sums: bool = False):
     """``bwd_stats = (y, mean, scale, shift, mask_mode)`` of the BatchNorm layer that consumes the
     result ``g``: the epilogue also accumulates that layer's backward sums (what
     :func:`bn_bwd_reduce` would compute from ``g`` and ``y`` in a pass of its own); pass
-    ``prereduced=True`` to :func:`bn_bwd_reduce` afterwards."""
+    ``prereduced=True`` to :func:`bn_bwd_reduce` afterwards.  ``out_sums``: the epilogue adds up the result
+    itself per channel instead (no other tensor is read); :func:`grad_sums` collects the sums."""
     dy = _bf16c(dy, "conv_dgrad dy")
     if wt is None:
         raise ValueError("conv_dgrad: the hip backend needs the transposed weight copy wt[Cin,R,S,Cout]")
@@ -623,10 +625,15 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
                  bshift if recompute else None)
     if bstat is not None and mask_src is not None and not bits:
         raise ValueError("conv_dgrad: with bwd_stats the ReLU mask must be given in packed form (relu_bits)")
+    gacc = None
+    if out_sums:
+        if bstat is not None:
+            raise ValueError("conv_dgrad: out_sums and bwd_stats share the epilogue's statistics path")
+        gacc = _accumulator(dy.device, Ci, "gsum")
     if stride == 1:
         _igemm(dy, wt, dx, B * Hi * Wi, Ho, Wo, Co, Co, Hi, Wi, 1, Hi, Wi, 1, 0, 0, Ci, Ci, R * S * Co,
                _dgrad_taps(R, S, pad, 1, 0, 0), addend=addend, mask=mask_src, tile=tile, bstat=bstat, mask_bits=bits,
-               addend_half=addend_half)
+               addend_half=addend_half, stat_acc=gacc)
         return dx
     for ph in range(stride):
         for pw in range(stride):
@@ -636,8 +643,23 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
                 continue
             _igemm(dy, wt, dx, B * Hg * Wg, Ho, Wo, Co, Co, Hg, Wg, 1, Hi, Wi, stride, ph, pw, Ci, Ci, R * S * Co,
                    _dgrad_taps(R, S, pad, stride, ph, pw), addend=addend, mask=mask_src, tile=tile, bstat=bstat,
-                   mask_bits=bits, addend_half=addend_half)
+                   mask_bits=bits, addend_half=addend_half, stat_acc=gacc)
     return dx
+
+
+def grad_sums(C: int, device: torch.device) -> torch.Tensor:
+    """``[2, C]``: per-channel sum and sum of squares of the last gradient produced with
+    ``conv_dgrad(out_sums=True)`` (collects and re-zeroes the accumulator)."""
+    out = torch.empty(2, C, dtype=torch.float32, device=device)
+    _check(_lib.pdt_bn_moments(_p(_accumulator(device, C, "gsum")), _p(out), C, 1.0, _stream()), "pdt_bn_moments")
+    return out
+
+
+def zeros_f32(shape, device: torch.device) -> torch.Tensor:
+    """A zeroed fp32 tensor through the library's own kernel (so that a recorded step zeroes it again)."""
+    t = torch.empty(shape, dtype=torch.float32, device=device)
+    _check(_lib.pdt_zero_f32(_p(t), t.numel(), _stream()), "pdt_zero_f32")
+    return t
 
 
 # Measurement aid (bench/ablate.sh): PDT_ABLATE=wgrad drops every weight-gradient launch, so the step
@@ -890,6 +912,22 @@ def bn_fold_prepare(sums, scale, invstd, mean, inv_count: float, w: torch.Tensor
     return BnFold(wfold, bias, coef, C, N)
 
 
+def bn_fold_sums(prod: torch.Tensor, w: torch.Tensor, s0: torch.Tensor, mean, invstd, dgamma=None, dbeta=None):
+    """The ``[2, N]`` backward sums of the BatchNorm behind ``y = a . w^T`` from ``s0 = sum g`` and the unscaled
+    weight-gradient product ``prod = g^T a`` (``[N, 1, 1, C]`` fp32): ``sum g y = sum_c w[n, c] prod[n, c]``.
+    Also ``dbeta += s0``, ``dgamma += sum g xhat`` like :func:`bn_bwd_reduce`."""
+    w = _bf16c(w, "bn_fold_sums w")
+    _f32c(prod, "bn_fold_sums prod")
+    N, C = w.shape[0], w.shape[-1]
+    if w.numel() != N * C or prod.numel() != N * C or C % 8:
+        raise ValueError("bn_fold_sums: w / prod must be [N, 1, 1, C] with C a multiple of 8")
+    sums = torch.empty(2, N, dtype=torch.float32, device=w.device)
+    rc = _lib.pdt_bnfold_sums(_p(prod), _p(w), _p(s0), _p(mean), _p(invstd), _p(sums), _p(dgamma), _p(dbeta), C, N,
+                              _stream())
+    _check(rc, "pdt_bnfold_sums")
+    return sums
+
+
 def conv_dgrad_folded(g: torch.Tensor, a_in: torch.Tensor, fold: BnFold, bwd_stats=None,
                       out: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
     """Data gradient of ``conv1x1 -> BatchNorm`` w.r.t. the convolution input ``a_in`` from ``g``, the gradient
@@ -923,10 +961,12 @@ def conv_dgrad_folded(g: torch.Tensor, a_in: torch.Tensor, fold: BnFold, bwd_sta
     return dx
 
 
-def conv_wgrad_folded(a_in: torch.Tensor, g: torch.Tensor, fold: BnFold, w: torch.Tensor, dw: torch.Tensor) -> None:
+def conv_wgrad_folded(a_in: torch.Tensor, g: torch.Tensor, fold: BnFold, w: torch.Tensor, dw: torch.Tensor,
+                      prod: Optional[torch.Tensor] = None) -> None:
     """``dw += (A o g + B o y + K)^T . a_in`` without the tensor in parentheses and without ``y``: the scaled
     product ``A o (g^T a)``, the Gram matrix ``a^T a`` (an ordinary weight-gradient launch with ``a`` on both
-    sides), the column means of ``a``, and the small correction kernel."""
+    sides), the column means of ``a``, and the small correction kernel.  ``prod``: the unscaled ``g^T a`` is
+    already there (see :func:`bn_fold_sums`); the correction kernel scales and adds it."""
     if _ABLATE_WGRAD:
         return
     a_in = _bf16c(a_in, "conv_wgrad_folded a_in")
@@ -949,9 +989,14 @@ def conv_wgrad_folded(a_in: torch.Tensor, g: torch.Tensor, fold: BnFold, w: torc
     gram = torch.empty(C, C, dtype=torch.float32, device=dev)
     _check(_lib.pdt_zero_f32(_p(gram), C * C, _stream()), "pdt_zero_f32")
     _wgrad(a_in, a_in, gram, rows, H, W, C, C, H, W, 1, C, C, C, taps)
-    # A o (g^T a) straight into the gradient buffer, then the correction
-    _wgrad(g, a_in, dw, rows, H, W, C, C, H, W, 1, N, N, C, taps, row_scale=fold.coef[0])
-    rc = _lib.pdt_bnfold_wgrad(_p(dw), _p(w), _p(gram), _p(mom), float(rows), _p(fold.coef), C, N, _stream())
+    if prod is None:
+        # A o (g^T a) straight into the gradient buffer, then the correction
+        _wgrad(g, a_in, dw, rows, H, W, C, C, H, W, 1, N, N, C, taps, row_scale=fold.coef[0])
+    else:
+        _f32c(prod, "conv_wgrad_folded prod")
+        if prod.numel() != N * C:
+            raise ValueError("conv_wgrad_folded: prod must be [N, 1, 1, C]")
+    rc = _lib.pdt_bnfold_wgrad(_p(dw), _p(w), _p(gram), _p(mom), float(rows), _p(fold.coef), _p(prod), C, N, _stream())
     _check(rc, "pdt_bnfold_wgrad")
 
 # --------------------------------------------------------------------------- pooling

@@ -114,7 +114,7 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pa
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: Optional[torch.Tensor], in_shape, R: int, S: int,
                stride: int, pad: int, addend: Optional[torch.Tensor] = None,
                relu_mask: Optional[torch.Tensor] = None, relu_bits: Optional[torch.Tensor] = None,
-               addend_half: bool = False, **_) -> torch.Tensor:
+               addend_half: bool = False, out_sums: bool = False, **_) -> torch.Tensor:
     """``dx = (conv_transpose(dy, w) [+ addend]) [* (relu_mask > 0)]`` ; ``in_shape = (B, Hi, Wi, Ci)``.
     ``relu_bits``: the same mask in packed form (see :func:`bn_apply`).
 
@@ -136,7 +136,22 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: Optional[torch.Tensor], in
         dx = dx * _unpack_bits(relu_bits)
     elif relu_mask is not None:
         dx = dx * (relu_mask > 0)
+    if out_sums:         # per-channel sum / sum of squares of the stored result, collected by grad_sums
+        d2 = dx.float().reshape(-1, Ci)
+        _grad_sums[Ci] = torch.stack([d2.sum(0), (d2 * d2).sum(0)])
     return dx
+
+
+_grad_sums = {}
+
+
+def grad_sums(C: int, device=None) -> torch.Tensor:
+    """``[2, C]`` sums left by the last ``conv_dgrad(out_sums=True)`` with ``C`` output channels."""
+    return _grad_sums.pop(C)
+
+
+def zeros_f32(shape, device) -> torch.Tensor:
+    return torch.zeros(shape, dtype=torch.float32, device=device)
 
 
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, R: int, S: int, stride: int, pad: int, dw: torch.Tensor,
@@ -330,6 +345,19 @@ def bn_fold_prepare(sums, scale, invstd, mean, inv_count: float, w: torch.Tensor
     return BnFold(wfold, K @ w2, torch.stack([A, Bc, K]).contiguous(), C, N)
 
 
+def bn_fold_sums(prod: torch.Tensor, w: torch.Tensor, s0: torch.Tensor, mean, invstd, dgamma=None, dbeta=None):
+    """``[s0, s1]`` with ``s1 = sum g * xhat = invstd * (sum_c w[n, c] prod[n, c] - mean * s0)`` from the unscaled
+    weight-gradient product ``prod = g^T a`` -- because ``y = a . w^T``, ``sum_m g y`` needs neither ``g`` nor
+    ``y`` again.  ``dbeta += s0``, ``dgamma += s1`` (local sums, like :func:`bn_bwd_reduce`)."""
+    N, C = w.shape[0], w.shape[-1]
+    s1 = invstd * ((w.reshape(N, C).float() * prod.reshape(N, C)).sum(1) - mean * s0)
+    if dbeta is not None:
+        dbeta.add_(s0)
+    if dgamma is not None:
+        dgamma.add_(s1)
+    return torch.stack([s0, s1])
+
+
 def conv_dgrad_folded(g: torch.Tensor, a_in: torch.Tensor, fold: BnFold, bwd_stats=None,
                       out: Optional[torch.Tensor] = None, **_) -> torch.Tensor:
     """``g . (A o w) + a_in . S + bias`` (see :func:`bn_fold_prepare`); ``bwd_stats`` is a fused backend's
@@ -344,13 +372,16 @@ def conv_dgrad_folded(g: torch.Tensor, a_in: torch.Tensor, fold: BnFold, bwd_sta
     return dx
 
 
-def conv_wgrad_folded(a_in: torch.Tensor, g: torch.Tensor, fold: BnFold, w: torch.Tensor, dw: torch.Tensor) -> None:
-    """``dw += A o (g^T a) + B o (w . (a^T a)) + K (x) colsum(a)`` (see :func:`bn_fold_prepare`)."""
+def conv_wgrad_folded(a_in: torch.Tensor, g: torch.Tensor, fold: BnFold, w: torch.Tensor, dw: torch.Tensor,
+                      prod: Optional[torch.Tensor] = None) -> None:
+    """``dw += A o (g^T a) + B o (w . (a^T a)) + K (x) colsum(a)`` (see :func:`bn_fold_prepare`); ``prod``: the
+    product ``g^T a`` when it has been formed already (:func:`bn_fold_sums`)."""
     N, C = fold.N, fold.C
     a2, g2 = a_in.float().reshape(-1, C), g.float().reshape(-1, N)
     A, Bc, K = fold.coef[0], fold.coef[1], fold.coef[2]
     gram = a2.t() @ a2
-    upd = A[:, None] * (g2.t() @ a2) + Bc[:, None] * (w.reshape(N, C).float() @ gram) + K[:, None] * a2.sum(0)[None, :]
+    p2 = prod.reshape(N, C) if prod is not None else g2.t() @ a2
+    upd = A[:, None] * p2 + Bc[:, None] * (w.reshape(N, C).float() @ gram) + K[:, None] * a2.sum(0)[None, :]
     dw.add_(upd.reshape(dw.shape))
 
 # ---------------------------------------------------------------------------- pooling

@@ -56,6 +56,28 @@ def test_folded_reference_ops_match_the_plain_sequence():
     assert torch.allclose(dw_f, 2 * dw, rtol=1e-4, atol=2e-5 * dw.abs().max().item())
 
 
+def test_backward_sums_from_the_weight_gradient_product():
+    """sum g * xhat from s0 = sum g and the product g^T a equals the reduction over g and y."""
+    a, w, y, mean, invstd, scale, shift, g = _layer(3, 6, 16, 64, torch.float32, torch.device("cpu"), seed=4)
+    sums, inv, dx, dw = _plain(a, w, y, mean, invstd, scale, shift, g)
+    prod = torch.zeros(64, 1, 1, 16)
+    ref.conv_wgrad(a, g, 1, 1, 1, 0, prod)
+    dgamma, dbeta = torch.zeros(64), torch.zeros(64)
+    got = ref.bn_fold_sums(prod, w, g.reshape(-1, 64).sum(0), mean, invstd, dgamma, dbeta)
+    assert torch.allclose(got, sums, rtol=1e-4, atol=1e-4 * sums.abs().max().item())
+    assert torch.equal(dbeta, got[0]) and torch.equal(dgamma, got[1])
+    # ... and the weight gradient assembled from that same product
+    fold = ref.bn_fold_prepare(got, scale, invstd, mean, inv, w)
+    dw_f = torch.zeros_like(dw)
+    ref.conv_wgrad_folded(a, g, fold, w, dw_f, prod=prod)
+    assert torch.allclose(dw_f, dw, rtol=1e-4, atol=1e-5 * dw.abs().max().item())
+    # conv_dgrad(out_sums=True) leaves the sums of what it returns
+    wt = None
+    d = ref.conv_dgrad(g, w, wt, tuple(a.shape), 1, 1, 1, 0, out_sums=True)
+    gs = ref.grad_sums(16)
+    assert torch.allclose(gs[0], d.reshape(-1, 16).sum(0), rtol=1e-5, atol=1e-5)
+
+
 def test_engine_with_and_without_the_folded_path(monkeypatch):
     """Same model, same batch: every gradient of a bottleneck network agrees between the two paths."""
     from pytorch_distributed_training_amd.engine.native_resnet import NativeResNet
@@ -66,16 +88,18 @@ def test_engine_with_and_without_the_folded_path(monkeypatch):
     img = torch.randn(4, 3, 32, 32)
     label = torch.randint(0, 10, (4,))
     grads = []
-    for on in ("1", "0"):
+    for on, product in (("1", "1"), ("1", "0"), ("0", "0")):
         monkeypatch.setenv("PDT_BN_FOLD", on)
+        monkeypatch.setenv("PDT_BN_FOLD_PRODUCT", product)
         eng = NativeResNet(get_spec("ResNet50", 10), torch.device("cpu"), ref, torch.float32)
         eng.load_state_dict(state)
-        assert eng._bn_fold == (on == "1")
+        assert eng._bn_fold == (on == "1") and eng._bn_fold_product == (product == "1")
         eng.forward_backward(img, label)
         grads.append(eng.params.g.clone())
     assert grads[0].abs().max() > 0
-    rel = (grads[0] - grads[1]).abs().max() / grads[1].abs().max()
-    assert rel < 2e-4, rel
+    for gfold in grads[:2]:
+        rel = (gfold - grads[2]).abs().max() / grads[2].abs().max()
+        assert rel < 2e-4, rel
 
 
 # ----------------------------------------------------------------------------------------------- GPU tier
@@ -136,6 +160,40 @@ def test_hip_folded_products_match_the_reference(hip, device, shape):
     hip.conv_wgrad_folded(a, g, fold, w, dw)
     assert rel_err(dw, 2 * dw_ref) < 5e-3
 
+    # the backward sums from s0 and the unscaled product, and the weight gradient assembled from that product
+    prod = hip.zeros_f32((N, 1, 1, C), device)
+    hip.conv_wgrad(a, g, 1, 1, 1, 0, prod)
+    s0 = g.float().reshape(-1, N).sum(0)
+    dgamma, dbeta = torch.zeros(N, device=device), torch.zeros(N, device=device)
+    got = hip.bn_fold_sums(prod, w, s0, mean, invstd, dgamma, dbeta)
+    want = ref.bn_fold_sums(prod, w, s0, mean, invstd)
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-4 * want.abs().max().item())
+    assert torch.allclose(got[1], sums[1], rtol=2e-2, atol=2e-2 * sums[1].abs().max().item())   # (y rounded to bf16)
+    assert torch.equal(dbeta, got[0]) and torch.equal(dgamma, got[1])
+    dw3 = torch.zeros_like(dw)
+    hip.conv_wgrad_folded(a, g, fold, w, dw3, prod=prod)
+    assert rel_err(dw3, dw_ref) < 5e-3
+
+
+@pytest.mark.gpu
+def test_hip_dgrad_leaves_the_sums_of_its_result(hip, device):
+    B, H, Ci, Co = 6, 14, 256, 64
+    torch.manual_seed(2)
+    dy = (torch.randn(B, H, H, Co, device=device) * 0.3).to(torch.bfloat16)
+    w = (torch.randn(Co, 1, 1, Ci, device=device) * 0.1).to(torch.bfloat16)
+    wt = torch.empty(Ci, 1, 1, Co, dtype=torch.bfloat16, device=device)
+    hip.transpose_weights(w, wt)
+    addend = (torch.randn(B, H, H, Ci, device=device) * 0.3).to(torch.bfloat16)
+    bits = hip.new_relu_bits(addend)
+    bits.copy_(torch.randint(0, 256, tuple(bits.shape), device=device, dtype=torch.uint8))
+    dx = hip.conv_dgrad(dy, w, wt, (B, H, H, Ci), 1, 1, 1, 0, addend=addend, relu_bits=bits, out_sums=True)
+    gs = hip.grad_sums(Ci, device)
+    d2 = dx.float().reshape(-1, Ci)
+    assert torch.allclose(gs[0], d2.sum(0), rtol=1e-3, atol=1e-3 * d2.sum(0).abs().max().item())
+    assert torch.allclose(gs[1], (d2 * d2).sum(0), rtol=1e-3, atol=1e-3)
+    assert rel_err(dx, ref.conv_dgrad(dy, w, None, (B, H, H, Ci), 1, 1, 1, 0, addend=addend, relu_bits=bits)) < 1.5e-2
+    assert hip.grad_sums(Ci, device).abs().max().item() == 0.0           # collected: the accumulator is clean again
+
 
 @pytest.mark.gpu
 def test_hip_engine_with_and_without_the_folded_path(hip, device, monkeypatch):
@@ -148,22 +206,24 @@ def test_hip_engine_with_and_without_the_folded_path(hip, device, monkeypatch):
     label = torch.randint(0, 10, (8,), device=device)
     grads, losses = [], []
     monkeypatch.setenv("PDT_BN_FOLD_MIN_MB", "0")        # fold every bottleneck block, however small its tensors
-    for on in ("1", "0"):
+    for on, product in (("1", "1"), ("1", "0"), ("0", "0")):
         monkeypatch.setenv("PDT_BN_FOLD", on)
-        eng = NativeResNet(get_spec("ResNet50", 10), device, hip, torch.bfloat16)
+        monkeypatch.setenv("PDT_BN_FOLD_PRODUCT", product)
+        eng = NativeResNet(get_spec("ResNet50", 10), device, hip, torch.bfloat16, hip_graphs=True)
         eng.load_state_dict(state)
-        assert eng._bn_fold == (on == "1")
-        losses.append(float(eng.forward_backward(img, label)))
-        torch.cuda.synchronize()
-        grads.append(eng.params.g.clone())
-    assert abs(losses[0] - losses[1]) < 1e-4            # the forward pass is untouched (statistics: float atomics)
-    # per parameter tensor: the two paths differ by bf16 rounding of different intermediates
-    eng_p = eng.params
-    worst = 0.0
-    for key, e in eng_p.entries.items():
-        a = grads[0][e.offset:e.offset + e.numel]
-        b = grads[1][e.offset:e.offset + e.numel]
-        cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
-        worst = max(worst, 1 - cos)
-        assert cos > 0.99, (key, cos)
-    assert worst < 1e-2
+        assert eng._bn_fold == (on == "1") and eng._bn_fold_product == (product == "1")
+        for _ in range(3):                               # eager, recorded, replayed
+            loss = float(eng.forward_backward(img, label))
+            torch.cuda.synchronize()
+            last = eng.params.g.clone()
+            eng.params.g.zero_()
+        losses.append(loss)
+        grads.append(last)
+    assert abs(losses[0] - losses[2]) < 1e-3 and abs(losses[1] - losses[2]) < 1e-3    # the forward pass is untouched
+    # per parameter tensor: the paths differ by bf16 rounding of different intermediates
+    for gfold in grads[:2]:
+        for key, e in eng.params.entries.items():
+            a = gfold[e.offset:e.offset + e.numel]
+            b = grads[2][e.offset:e.offset + e.numel]
+            cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+            assert cos > 0.99, (key, cos)
