@@ -198,6 +198,7 @@ class NativeResNet:
         # produces their incoming gradient only adds up the gradient itself and reads no BatchNorm input for them;
         # with that, a stride-1 projection shortcut is folded as well (PDT_BN_FOLD_PRODUCT=0: sums as before).
         self._bn_fold_product = self._bn_fold and os.environ.get("PDT_BN_FOLD_PRODUCT", "1") == "1"
+        self._colsum_pending: set = set()     # accumulators a forward pass filled and no backward has collected yet
         # Step replay (see .graphs): the second step of a batch signature is recorded, later ones
         # replay the record.  "list": a command list of the backend's own launches (default);
         # "graph": HIP graphs separated by host actions.  PDT_HIP_GRAPHS: 0 = off, 1 = on,
@@ -527,9 +528,29 @@ class NativeResNet:
         return y, scale, shift
 
     def _unit_forward(self, u: ConvBNSpec, x: torch.Tensor, residual: Optional[torch.Tensor], relu: bool,
-                      train: bool, pre=None) -> torch.Tensor:
+                      train: bool, pre=None, colsum_for: Optional[ConvBNSpec] = None) -> torch.Tensor:
+        """``colsum_for``: the unit that consumes the result, when its BatchNorm backward is going to be folded
+        (it wants the per-channel sums of this tensor, which the pass that writes it can add up for free)."""
         y, scale, shift = self._unit_conv_bn(u, x, train, pre)
+        if colsum_for is not None and train and self._will_fold(colsum_for, y):
+            slot = colsum_for.bn
+            if slot in self._colsum_pending:      # a training forward whose backward never ran: drop its sums
+                self.ops.colsum_take(slot, y.shape[-1], self.device)
+            self._colsum_pending.add(slot)
+            self._saved[f"colsum:{slot}"] = True
+            return self.ops.bn_apply(y, scale, shift, residual, relu, colsum_slot=slot)
         return self.ops.bn_apply(y, scale, shift, residual, relu)
+
+    def _will_fold(self, u: ConvBNSpec, x_in: torch.Tensor) -> bool:
+        """:meth:`_can_fold` before the unit has run: from its input (1x1 / stride 1: the output has the input's
+        pixels and ``u.cout`` channels)."""
+        if not self._bn_fold or u.ksize != 1 or u.stride != 1 or u.pad != 0:
+            return False
+        if (x_in.numel() // x_in.shape[-1]) * u.cout * x_in.element_size() < self._bn_fold_min_bytes:
+            return False
+        if getattr(self.ops, "name", "") != "hip":
+            return True
+        return u.cin % 64 == 0 and u.cout % 64 == 0 and u.cin <= self.ops.BN_FOLD_MAX_C
 
     # -- cache-sized batch slices ---------------------------------------------------------------
     def _n_slices(self, t: torch.Tensor) -> int:
@@ -603,7 +624,8 @@ class NativeResNet:
         for i, u in enumerate(b.units):
             p = pre.get(u.bn) if i == 0 else None
             if i < last:
-                out = self._unit_forward(u, out, None, True, train, p)
+                out = self._unit_forward(u, out, None, True, train, p,
+                                         colsum_for=b.units[last] if (i == last - 1 and last > 0) else None)
                 continue
             y, scale, shift = self._unit_conv_bn(u, out, train, p)
             tail = ("apply2", y, scale, shift, shortcut) if shortcut is not None else \
@@ -741,6 +763,9 @@ class NativeResNet:
         P, ops, red = self.params, self.ops, self.reducer
         key = f"{u.conv}.weight"
         kw = {"prod": prod} if prod is not None else {}
+        if self._saved.pop(f"colsum:{u.bn}", False):
+            kw["amean_slot"] = u.bn                 # the forward pass left the column sums of x behind
+            self._colsum_pending.discard(u.bn)
 
         def run() -> None:
             end = P.end_offset(key)

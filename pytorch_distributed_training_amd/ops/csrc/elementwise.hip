@@ -66,19 +66,25 @@ template <bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ y, const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
                                                         const bf16* __restrict__ res, bf16* __restrict__ out,
-                                                        unsigned char* __restrict__ bits, long long nvec, int cvec) {
+                                                        unsigned char* __restrict__ bits, long long nvec, int cvec,
+                                                        float* __restrict__ colsum, int nrep) {
     // bits (optional): one byte per 8-channel vector, bit k = [out channel k > 0] -- the ReLU mask
     // backward needs, 1/16 of the tensor it would otherwise re-read for the sign.
+    // colsum (optional): replica accumulator [nrep][2][C]; row 0 receives the per-channel sums of the values
+    // written (what the folded BatchNorm backward of the NEXT layer wants from this tensor, see bn_fold.hip).
+    __shared__ float red[256][8 + 1];
     long long stride = (long long)gridDim.x * blockDim.x;
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nvec) return;
+    if (t >= nvec && !colsum) return;
     // Walk the tensor from its END: the conv kernel that produced y wrote it front to back, so the
     // tail is what the memory-side cache still holds; and the front of `out`, written last here,
-    // is what the next conv reads first.
-    int c0 = (int)((nvec - 1 - t) % cvec) * 8;
-    float sc[8], sh[8];
+    // is what the next conv reads first.  nvec and the grid stride are multiples of cvec, so the
+    // channel group of a thread is fixed (and defined for threads past the end, too).
+    const int cg = cvec - 1 - (int)(t % cvec);
+    const int c0 = cg * 8;
+    float sc[8], sh[8], cs[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { sc[k] = scale[c0 + k]; sh[k] = shift[c0 + k]; }
+    for (int k = 0; k < 8; ++k) { sc[k] = scale[c0 + k]; sh[k] = shift[c0 + k]; cs[k] = 0.0f; }
     for (; t < nvec; t += stride) {
         const long long i = nvec - 1 - t;
         bf16x8 v = ld_stream_bf16x8(y + i * 8);      // not read again before backward
@@ -91,6 +97,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ 
             if (RES) f += bf2f(r[k]);
             if (RELU) f = fmaxf(f, 0.0f);
             o[k] = f2bf(f);
+            cs[k] += bf2f(o[k]);
         }
         st_bf16x8(out + i * 8, o);
         if (bits) {
@@ -100,22 +107,42 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ 
             bits[i] = (unsigned char)m;
         }
     }
+    if (!colsum) return;
+    // threads tid, tid + cvec, ... of the block share a channel group (256 % cvec == 0)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = cs[k];
+    __syncthreads();
+    const int C = cvec * 8;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = cvec - 1 - c / 8, k = c % 8;
+        float sum = 0.0f;
+        for (int r = g; r < 256; r += cvec) sum += red[r][k];
+        atomicAdd(colsum + (size_t)(blockIdx.x % nrep) * 2 * C + c, sum);
+    }
 }
 
-PDT_API int pdt_bn_apply(const void* y, const float* scale, const float* shift, const void* res, void* out, void* bits,
-                         long long rows, int C, int relu, hipStream_t s) {
+// colsum: optional replica accumulator [nrep][2][C] (see the kernel); not in deterministic mode (rows are shared)
+PDT_API int pdt_bn_apply_ex(const void* y, const float* scale, const float* shift, const void* res, void* out, void* bits,
+                            long long rows, int C, int relu, float* colsum, hipStream_t s) {
     // the grid stride (grid*256 vectors) must be a multiple of C/8 so channels stay fixed per thread
     if (C % 8 != 0 || C / 8 > 256 || 256 % (C / 8) != 0) return -1;
+    if (colsum && g_pdt_deterministic) return -9;
     long long nvec = rows * (C / 8);
     int cvec = C / 8;
     dim3 grid(ew_grid(nvec, 4)), block(256);
     const bf16* yy = (const bf16*)y; const bf16* rr = (const bf16*)res; bf16* oo = (bf16*)out;
     unsigned char* bb = (unsigned char*)bits;
-    if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, 0, s, yy, scale, shift, rr, oo, bb, nvec, cvec);
-    else if (res) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, 0, s, yy, scale, shift, rr, oo, bb, nvec, cvec);
-    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, block, 0, s, yy, scale, shift, rr, oo, bb, nvec, cvec);
-    else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, 0, s, yy, scale, shift, rr, oo, bb, nvec, cvec);
+    const int nrep = pdt_nrep();
+    if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, 0, s, yy, scale, shift, rr, oo, bb, nvec, cvec, colsum, nrep);
+    else if (res) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, 0, s, yy, scale, shift, rr, oo, bb, nvec, cvec, colsum, nrep);
+    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, block, 0, s, yy, scale, shift, rr, oo, bb, nvec, cvec, colsum, nrep);
+    else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, 0, s, yy, scale, shift, rr, oo, bb, nvec, cvec, colsum, nrep);
     return pdt_launch_status();
+}
+
+PDT_API int pdt_bn_apply(const void* y, const float* scale, const float* shift, const void* res, void* out, void* bits,
+                         long long rows, int C, int relu, hipStream_t s) {
+    return pdt_bn_apply_ex(y, scale, shift, res, out, bits, rows, C, relu, nullptr, s);
 }
 
 // Block tail with a projection shortcut: out = relu(y*scale + shift + y2*scale2 + shift2).  The

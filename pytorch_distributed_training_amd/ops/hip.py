@@ -40,6 +40,7 @@ def _sig(fn_name: str, *argtypes) -> None:
 
 _sig("pdt_sgd_step", _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _i, _vp)
 _sig("pdt_bn_apply", _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp)
+_sig("pdt_bn_apply_ex", _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp)
 _sig("pdt_bn_apply2", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp)
 _sig("pdt_bn_bwd_elemt", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _ll, _i, _i, _vp)
 _sig("pdt_input_pad", _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _vp)
@@ -655,6 +656,14 @@ def grad_sums(C: int, device: torch.device) -> torch.Tensor:
     return out
 
 
+def colsum_take(slot: str, C: int, device: torch.device) -> torch.Tensor:
+    """``[C]`` per-channel sums left by ``bn_apply(colsum_slot=slot)``; collects and re-zeroes the accumulator."""
+    out = torch.empty(2, C, dtype=torch.float32, device=device)
+    _check(_lib.pdt_bn_moments(_p(_accumulator(device, C, "colsum:" + slot)), _p(out), C, 1.0, _stream()),
+           "pdt_bn_moments")
+    return out[0]
+
+
 def zeros_f32(shape, device: torch.device) -> torch.Tensor:
     """A zeroed fp32 tensor through the library's own kernel (so that a recorded step zeroes it again)."""
     t = torch.empty(shape, dtype=torch.float32, device=device)
@@ -765,9 +774,11 @@ def _check_bits(bits, shape, what: str) -> None:
 
 
 def bn_apply(y, scale, shift, residual, relu: bool, out: Optional[torch.Tensor] = None,
-             bits_out: Optional[torch.Tensor] = None):
+             bits_out: Optional[torch.Tensor] = None, colsum_slot: Optional[str] = None):
     """``bits_out``: also receives ``[out > 0]`` packed one byte per 8 channels -- what the ReLU
-    backward of this tensor needs, at 1/16 of the tensor's size."""
+    backward of this tensor needs, at 1/16 of the tensor's size.  ``colsum_slot``: the per-channel sums of the
+    result are left in the accumulator of that name (for ``conv_wgrad_folded(amean_slot=...)`` of the layer that
+    consumes this tensor); ignored in deterministic mode."""
     y = _bf16c(y, "bn_apply y")
     C = y.shape[-1]
     out = _out_like(out, y.shape, y.device, "bn_apply")
@@ -777,8 +788,9 @@ def bn_apply(y, scale, shift, residual, relu: bool, out: Optional[torch.Tensor] 
         _check_bits(bits_out, y.shape, "bn_apply bits_out")
     if _ABLATE_APPLY and residual is None:
         return out
-    rc = _lib.pdt_bn_apply(_p(y), _p(scale), _p(shift), _p(residual), _p(out), _p(bits_out), y.numel() // C, C,
-                           int(bool(relu)), _stream())
+    acc = _accumulator(y.device, C, "colsum:" + colsum_slot) if (colsum_slot and not _deterministic) else None
+    rc = _lib.pdt_bn_apply_ex(_p(y), _p(scale), _p(shift), _p(residual), _p(out), _p(bits_out), y.numel() // C, C,
+                              int(bool(relu)), _p(acc), _stream())
     _check(rc, "pdt_bn_apply")
     return out
 
@@ -962,11 +974,12 @@ def conv_dgrad_folded(g: torch.Tensor, a_in: torch.Tensor, fold: BnFold, bwd_sta
 
 
 def conv_wgrad_folded(a_in: torch.Tensor, g: torch.Tensor, fold: BnFold, w: torch.Tensor, dw: torch.Tensor,
-                      prod: Optional[torch.Tensor] = None) -> None:
+                      prod: Optional[torch.Tensor] = None, amean_slot: Optional[str] = None) -> None:
     """``dw += (A o g + B o y + K)^T . a_in`` without the tensor in parentheses and without ``y``: the scaled
     product ``A o (g^T a)``, the Gram matrix ``a^T a`` (an ordinary weight-gradient launch with ``a`` on both
     sides), the column means of ``a``, and the small correction kernel.  ``prod``: the unscaled ``g^T a`` is
-    already there (see :func:`bn_fold_sums`); the correction kernel scales and adds it."""
+    already there (see :func:`bn_fold_sums`); the correction kernel scales and adds it.  ``amean_slot``: the
+    column sums of ``a_in`` were left in that accumulator by ``bn_apply(colsum_slot=...)``."""
     if _ABLATE_WGRAD:
         return
     a_in = _bf16c(a_in, "conv_wgrad_folded a_in")
@@ -981,8 +994,11 @@ def conv_wgrad_folded(a_in: torch.Tensor, g: torch.Tensor, fold: BnFold, w: torc
     dev = a_in.device
     taps = _one_tap()
     # column means of a
-    acc = _accumulator(dev, C, "fold")
-    _check(_lib.pdt_bn_stats_accum(_p(a_in), None, _p(acc), rows, C, _stream()), "pdt_bn_stats_accum")
+    if amean_slot and not _deterministic:
+        acc = _accumulator(dev, C, "colsum:" + amean_slot)
+    else:
+        acc = _accumulator(dev, C, "fold")
+        _check(_lib.pdt_bn_stats_accum(_p(a_in), None, _p(acc), rows, C, _stream()), "pdt_bn_stats_accum")
     mom = torch.empty(2, C, dtype=torch.float32, device=dev)
     _check(_lib.pdt_bn_moments(_p(acc), _p(mom), C, 1.0 / rows, _stream()), "pdt_bn_moments")
     # G = a^T a

@@ -150,6 +150,11 @@ def grad_sums(C: int, device=None) -> torch.Tensor:
     return _grad_sums.pop(C)
 
 
+def colsum_take(slot: str, C: int, device=None):
+    """(fused backends: the sums ``bn_apply(colsum_slot=slot)`` left behind; nothing is kept here)"""
+    return None
+
+
 def zeros_f32(shape, device) -> torch.Tensor:
     return torch.zeros(shape, dtype=torch.float32, device=device)
 
@@ -225,8 +230,10 @@ def _unpack_bits(bits: torch.Tensor) -> torch.Tensor:
 
 
 def bn_apply(y: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, residual: Optional[torch.Tensor],
-             relu: bool, bits_out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``bits_out``: also receives ``[out > 0]``, bit k of byte j = channel ``8j + k``."""
+             relu: bool, bits_out: Optional[torch.Tensor] = None, colsum_slot: Optional[str] = None) -> torch.Tensor:
+    """``bits_out``: also receives ``[out > 0]``, bit k of byte j = channel ``8j + k``.  ``colsum_slot``: a fused
+    backend leaves the per-channel sums of the result under that name for :func:`conv_wgrad_folded`; this backend
+    recomputes them there."""
     out = y.float() * scale + shift
     if residual is not None:
         out = out + residual.float()
@@ -373,7 +380,7 @@ def conv_dgrad_folded(g: torch.Tensor, a_in: torch.Tensor, fold: BnFold, bwd_sta
 
 
 def conv_wgrad_folded(a_in: torch.Tensor, g: torch.Tensor, fold: BnFold, w: torch.Tensor, dw: torch.Tensor,
-                      prod: Optional[torch.Tensor] = None) -> None:
+                      prod: Optional[torch.Tensor] = None, amean_slot: Optional[str] = None) -> None:
     """``dw += A o (g^T a) + B o (w . (a^T a)) + K (x) colsum(a)`` (see :func:`bn_fold_prepare`); ``prod``: the
     product ``g^T a`` when it has been formed already (:func:`bn_fold_sums`)."""
     N, C = fold.N, fold.C

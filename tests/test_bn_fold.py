@@ -176,6 +176,21 @@ def test_hip_folded_products_match_the_reference(hip, device, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 7, 64), (64, 28, 128), (5, 9, 512)])
+def test_hip_bn_apply_leaves_the_column_sums_of_its_result(hip, device, shape):
+    B, H, C = shape
+    torch.manual_seed(B + C)
+    y = torch.randn(B, H, H, C, device=device).to(torch.bfloat16)
+    scale, shift = torch.rand(C, device=device) + 0.5, torch.randn(C, device=device) * 0.3
+    out = hip.bn_apply(y, scale, shift, None, True, colsum_slot="test")
+    assert rel_err(out, ref.bn_apply(y, scale, shift, None, True)) < 1e-2
+    got = hip.colsum_take("test", C, device)
+    want = out.float().reshape(-1, C).sum(0)
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-3)
+    assert hip.colsum_take("test", C, device).abs().max().item() == 0.0
+
+
+@pytest.mark.gpu
 def test_hip_dgrad_leaves_the_sums_of_its_result(hip, device):
     B, H, Ci, Co = 6, 14, 256, 64
     torch.manual_seed(2)
