@@ -745,11 +745,12 @@ class NativeResNet:
         # (the deferred weight-gradient closures of the RCCL overlap mode are whole-layer units)
         return self._slice_bytes > 0 and not (self.sync_bn and self.syncbn_overlap and self._xgmi is None)
 
-    def _can_fold(self, u: ConvBNSpec, y: torch.Tensor) -> bool:
+    def _can_fold(self, u: ConvBNSpec, y: torch.Tensor, strided: bool = False) -> bool:
         """The unit's BatchNorm backward is folded into its convolution's gradient products: a 1x1 / stride 1
         convolution with channel counts the kernels take (every bottleneck block's last unit) whose output
-        ``y`` is large enough for the fold to pay."""
-        if not self._bn_fold or u.ksize != 1 or u.stride != 1 or u.pad != 0:
+        ``y`` is large enough for the fold to pay.  ``strided``: a stride-2 one (a projection shortcut), for
+        which the caller subsamples the input first."""
+        if not self._bn_fold or u.ksize != 1 or u.stride != (2 if strided else 1) or u.pad != 0:
             return False
         if y.numel() * y.element_size() < self._bn_fold_min_bytes:
             return False
@@ -893,6 +894,14 @@ class NativeResNet:
                 # (same g as the block's last BatchNorm: the same s0)
                 other = self._folded_tail_backward(d, None, ctx, g, False, s0)
                 dyd = None
+            elif s0 is not None and self._half_addend and Hx % 2 == 0 and Wx % 2 == 0 \
+                    and self._can_fold(d, ctx.y, strided=True):
+                # a stride-2 shortcut reads the even pixels only: on those, made dense once, it is a stride-1 unit,
+                # and its data gradient stays at half resolution like the unfolded one below
+                ctx.x_in = ops.subsample2(x_block)
+                other = self._folded_tail_backward(d, None, ctx, g, False, s0)
+                dyd = None
+                half = True
             else:
                 dyd = self._bn_backward(d, ctx, g, None, MASK_NONE)
                 keyd = f"{d.conv}.weight"

@@ -748,6 +748,34 @@ PDT_API int pdt_stem_unpack_add(const float* dwp, float* dw, int Co, hipStream_t
 }
 
 
+// ------------------------------------------------------------------------------------------
+// out[b][y][x][:] = in[b][2y][2x][:]  -- the pixels a stride-2 1x1 convolution reads, made dense (so that the products
+// of a folded projection shortcut, bn_fold.hip, see an ordinary row-aligned operand)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void subsample2_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int Ho,
+                                                          int Wo, int cvec, long long nvec) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const int cv = (int)(i % cvec);
+        long long pix = i / cvec;
+        const int x = (int)(pix % Wo);
+        pix /= Wo;
+        const int y = (int)(pix % Ho);
+        const long long b = pix / Ho;
+        const long long src = ((b * (2 * Ho) + 2 * y) * (2 * Wo) + 2 * x) * cvec + cv;
+        st_bf16x8(out + i * 8, ld_bf16x8(in + src * 8));
+    }
+}
+
+PDT_API int pdt_subsample2(const void* in, void* out, int B, int H, int W, int C, hipStream_t s) {
+    if (C % 8 != 0 || (H & 1) || (W & 1) || B <= 0) return -1;
+    const long long nvec = (long long)B * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(subsample2_kernel, dim3(ew_grid(nvec, 2)), dim3(256), 0, s, (const bf16*)in, (bf16*)out, H / 2, W / 2,
+                       C / 8, nvec);
+    return pdt_launch_status();
+}
+
+
 // ---- small runtime helpers (kept behind the C ABI so a recorded step can replay them) ---------
 __global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long long n) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

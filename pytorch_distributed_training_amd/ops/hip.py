@@ -94,6 +94,7 @@ _sig("pdt_accumulator_rows")
 
 _sig("pdt_transpose_w_batched", _vp, _vp, _vp, _i, _i, _vp)
 _sig("pdt_zero_f32", _vp, _ll, _vp)
+_sig("pdt_subsample2", _vp, _vp, _i, _i, _i, _i, _vp)
 _sig("pdt_event_create", ctypes.POINTER(ctypes.c_void_p))
 _sig("pdt_event_destroy", _vp)
 _sig("pdt_stream_wait_stream", _vp, _vp, _vp)
@@ -662,6 +663,15 @@ def colsum_take(slot: str, C: int, device: torch.device) -> torch.Tensor:
     _check(_lib.pdt_bn_moments(_p(_accumulator(device, C, "colsum:" + slot)), _p(out), C, 1.0, _stream()),
            "pdt_bn_moments")
     return out[0]
+
+
+def subsample2(x: torch.Tensor) -> torch.Tensor:
+    """``x[:, ::2, ::2]`` of an NHWC tensor with even height and width, dense."""
+    x = _bf16c(x, "subsample2")
+    B, H, W, C = x.shape
+    out = torch.empty(B, H // 2, W // 2, C, dtype=x.dtype, device=x.device)
+    _check(_lib.pdt_subsample2(_p(x), _p(out), B, H, W, C, _stream()), "pdt_subsample2")
+    return out
 
 
 def zeros_f32(shape, device: torch.device) -> torch.Tensor:

@@ -155,6 +155,11 @@ def colsum_take(slot: str, C: int, device=None):
     return None
 
 
+def subsample2(x: torch.Tensor) -> torch.Tensor:
+    """``x[:, ::2, ::2]`` of an NHWC tensor, dense: the pixels a stride-2 1x1 convolution reads."""
+    return x[:, ::2, ::2].contiguous()
+
+
 def zeros_f32(shape, device) -> torch.Tensor:
     return torch.zeros(shape, dtype=torch.float32, device=device)
 

@@ -191,6 +191,12 @@ def test_hip_bn_apply_leaves_the_column_sums_of_its_result(hip, device, shape):
 
 
 @pytest.mark.gpu
+def test_hip_subsample2(hip, device):
+    x = torch.randn(3, 10, 6, 64, device=device).to(torch.bfloat16)
+    assert torch.equal(hip.subsample2(x), ref.subsample2(x))
+
+
+@pytest.mark.gpu
 def test_hip_dgrad_leaves_the_sums_of_its_result(hip, device):
     B, H, Ci, Co = 6, 14, 256, 64
     torch.manual_seed(2)
