@@ -84,7 +84,7 @@ def _entry(name, a):
         images = M // max(Hg * Wg, 1)
         return dict(kind="wgrad", bytes=M * ldy * 2 + images * Hi * Wi * ps * 2 + N * wrow * 4,
                     flops=2 * M * N * T * Ci, desc=f"M{M} N{N} K{T}x{Ci}")
-    if name == "pdt_bn_apply":
+    if name in ("pdt_bn_apply", "pdt_bn_apply_ex"):
         y, sc, sh, res, out, bits, rows, C, relu = a[:9]
         return dict(kind="bn_apply", bytes=rows * C * 2 * (3 if res else 2) + (rows * C // 8 if bits else 0), flops=0,
                     desc=f"rows{rows} C{C}")
@@ -127,7 +127,7 @@ KERNEL_OF = {
     "pdt_conv_igemm": "igemm_kernel", "pdt_conv_igemm_bstats": "igemm_kernel", "pdt_conv_wgrad": "wgrad_",
     "pdt_conv_dma": "conv_dma_kernel", "pdt_conv_dma_ex": "conv_dma_kernel", "pdt_conv_wgrad_ex": "wgrad_",
     "pdt_bnfold_prepare": "bnfold_prepare_kernel", "pdt_bnfold_wgrad": "bnfold_wgrad_kernel",
-    "pdt_bnfold_sums": "bnfold_sums_kernel",
+    "pdt_bnfold_sums": "bnfold_sums_kernel", "pdt_bn_apply_ex": "bn_apply_kernel", "pdt_subsample2": "subsample2_kernel",
     "pdt_bn_apply": "bn_apply_kernel", "pdt_bn_apply2": "bn_apply2_kernel", "pdt_bn_bwd_elemt": "bn_bwd_elemt_kernel",
     "pdt_bn_bwd_reduce_accum": "bn_bwd_reduce_kernel", "pdt_bn_stats_accum": "bn_stats_kernel",
     "pdt_bn_moments": "bn_moments_kernel", "pdt_bn_finalize": "bn_finalize_kernel",
