@@ -60,6 +60,18 @@ def test_two_deterministic_runs_end_bit_identical(device):
     assert all(l == l for l in l1)
 
 
+def test_two_deterministic_runs_with_every_batchnorm_backward_folded(device, monkeypatch):
+    """The folded BatchNorm backward (forced onto every bottleneck block, however small) keeps the guarantee: its
+    products go through the slab weight gradient, its small kernels have one writer per element."""
+    monkeypatch.setenv("PDT_BN_FOLD_MIN_MB", "0")
+    p1, rm1, rv1, l1, _ = _run(device, True)
+    p2, rm2, rv2, l2, _ = _run(device, True)
+    assert l1 == l2, (l1, l2)
+    assert torch.equal(p1, p2), f"{(p1 != p2).sum().item()} of {p1.numel()} parameters differ"
+    assert torch.equal(rm1, rm2) and torch.equal(rv1, rv2)
+    assert all(l == l for l in l1)
+
+
 def test_deterministic_run_tracks_the_fast_path(device):
     """Same math, different summation order: the first loss agrees to bf16 noise and the gradients next to the
     loss point the same way.  (Deeper in the network nothing tight can be asked: statistics that differ in their

@@ -25,15 +25,15 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _engine(sync_bn, bucket_cap_mb=4.0, overlap=False):
+def _engine(sync_bn, bucket_cap_mb=4.0, overlap=False, model="ResNet18"):
     from pytorch_distributed_training_amd.engine import NativeResNet
     from pytorch_distributed_training_amd.models import get_model, get_spec
     from pytorch_distributed_training_amd.ops import ref
 
     torch.manual_seed(7)
-    eng = NativeResNet(get_spec("ResNet18", 10), torch.device("cpu"), ref, torch.float32, sync_bn=sync_bn,
+    eng = NativeResNet(get_spec(model, 10), torch.device("cpu"), ref, torch.float32, sync_bn=sync_bn,
                        bucket_cap_mb=bucket_cap_mb, first_bucket_mb=0.25, syncbn_overlap=overlap)
-    eng.load_state_dict(get_model("ResNet18", 10).state_dict())
+    eng.load_state_dict(get_model(model, 10).state_dict())
     return eng
 
 
@@ -106,6 +106,39 @@ def test_data_parallel_equivalence(tmp_path, sync_bn, overlap):
         assert not torch.equal(r0["rm"], r1["rm"])           # local statistics differ per rank
     err = (r0["grads"] - ref_grads).norm() / ref_grads.norm()
     assert err.item() < 2e-3, err.item()
+
+
+def _fold_worker(rank, world, port, out_dir):
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    x, y = _data()
+    out = {}
+    for fold in ("1", "0"):
+        os.environ["PDT_BN_FOLD"] = fold
+        eng = _engine(True, model="ResNet50")
+        assert eng._bn_fold == (fold == "1") and eng._bn_fold_product == (fold == "1")
+        eng.broadcast_state(0)
+        out["loss" + fold] = eng.forward_backward(x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4])
+        out["grads" + fold] = eng.params.g.clone() * eng.reducer.grad_scale
+    torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_syncbn_with_folded_batchnorm_backward(tmp_path):
+    """Bottleneck network on two ranks: the BatchNorm backward of block tails and projection shortcuts is folded
+    into their convolutions and takes its sums from the weight-gradient product; under SyncBN the local [s0, s1] of
+    every folded unit are all-reduced.  Compared with the SAME two-rank run without the fold: the forward passes
+    are identical, so what differs is backward rounding only.  (Against ONE process on the concatenated batch the
+    gradients of this 53-BatchNorm network agree to about a per cent with or without the fold: at 8 samples its
+    forward pass amplifies a 1e-7 change of the input into 1e-2 of the gradient.)"""
+    port = _free_port()
+    mp.spawn(_fold_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    for fold in ("1", "0"):
+        assert torch.equal(r0["grads" + fold], r1["grads" + fold])          # replicas agree bit for bit
+    assert r0["loss1"].item() == r0["loss0"].item()
+    err = (r0["grads1"] - r0["grads0"]).norm() / r0["grads0"].norm()
+    assert err.item() < 1e-4, err.item()
 
 
 def _trainer_cfg(tmp_path, extra=None):
