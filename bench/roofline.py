@@ -127,7 +127,8 @@ KERNEL_OF = {
     "pdt_conv_igemm": "igemm_kernel", "pdt_conv_igemm_bstats": "igemm_kernel", "pdt_conv_wgrad": "wgrad_",
     "pdt_conv_dma": "conv_dma_kernel", "pdt_conv_dma_ex": "conv_dma_kernel", "pdt_conv_wgrad_ex": "wgrad_",
     "pdt_bnfold_prepare": "bnfold_prepare_kernel", "pdt_bnfold_wgrad": "bnfold_wgrad_kernel",
-    "pdt_bnfold_sums": "bnfold_sums_kernel", "pdt_bn_apply_ex": "bn_apply_kernel", "pdt_subsample2": "subsample2_kernel",
+    "pdt_bnfold_sums": "bnfold_sums_kernel", "pdt_bnfold_fwd_stats": "bnfold_fwd_stats_kernel",
+    "pdt_bnfold_scale_weights": "bnfold_scale_weights_kernel", "pdt_bn_apply_ex": "bn_apply_kernel", "pdt_subsample2": "subsample2_kernel",
     "pdt_bn_apply": "bn_apply_kernel", "pdt_bn_apply2": "bn_apply2_kernel", "pdt_bn_bwd_elemt": "bn_bwd_elemt_kernel",
     "pdt_bn_bwd_reduce_accum": "bn_bwd_reduce_kernel", "pdt_bn_stats_accum": "bn_stats_kernel",
     "pdt_bn_moments": "bn_moments_kernel", "pdt_bn_finalize": "bn_finalize_kernel",

@@ -83,11 +83,15 @@ def backward_param_order(spec: ResNetSpec) -> List[str]:
 class _UnitCtx:
     """Tensors a conv+BN unit keeps from forward for its backward."""
 
-    __slots__ = ("x_in", "y", "scale", "shift", "mean", "invstd", "count")
+    __slots__ = ("x_in", "y", "scale", "shift", "mean", "invstd", "count", "gram", "mom", "y_bytes")
 
     def __init__(self) -> None:
         self.x_in = self.y = self.scale = self.shift = self.mean = self.invstd = None
         self.count = 0
+        # a unit whose output was never materialised (fused block tail): the Gram matrix and column means of its
+        # input, kept for the folded backward, and the size its output would have had
+        self.gram = self.mom = None
+        self.y_bytes = 0
 
 
 class NativeResNet:
@@ -199,6 +203,11 @@ class NativeResNet:
         # with that, a stride-1 projection shortcut is folded as well (PDT_BN_FOLD_PRODUCT=0: sums as before).
         self._bn_fold_product = self._bn_fold and os.environ.get("PDT_BN_FOLD_PRODUCT", "1") == "1"
         self._colsum_pending: set = set()     # accumulators a forward pass filled and no backward has collected yet
+        # Block tails in ONE kernel in forward: the batch statistics of a 1x1 convolution's output follow from the
+        # Gram matrix of its input (which the folded backward wants anyway), so BatchNorm is folded into the weights
+        # before the convolution runs and "+ shortcut, ReLU" is its epilogue (see _fused_tail_forward).
+        self._fwd_fuse = self._bn_fold_product and os.environ.get("PDT_FWD_FUSE", "1") == "1" \
+            and hasattr(ops, "conv_fprop_fused_tail")
         # Step replay (see .graphs): the second step of a batch signature is recorded, later ones
         # replay the record.  "list": a command list of the backend's own launches (default);
         # "graph": HIP graphs separated by host actions.  PDT_HIP_GRAPHS: 0 = off, 1 = on,
@@ -609,12 +618,14 @@ class NativeResNet:
         that tensor is worth slicing.  Returns this block's output the same way."""
         ops = self.ops
         pre = {}
+        fuse_tail = train and self._can_fuse_tail(b, tuple(x[1].shape if isinstance(x, tuple) else x.shape))
         if isinstance(x, tuple):
-            users = [b.units[0]] + ([b.downsample] if b.downsample is not None else [])
+            # (a fused tail runs the projection shortcut itself, as a second operand of the last convolution)
+            users = [b.units[0]] + ([b.downsample] if (b.downsample is not None and not fuse_tail) else [])
             x, pre = self._apply_then_convs(x, users, train)
         shortcut = None                    # (y, scale, shift) of a projection shortcut, applied in the tail
         identity = x
-        if b.downsample is not None:
+        if b.downsample is not None and not fuse_tail:
             shortcut = self._unit_conv_bn(b.downsample, x, train, pre.get(b.downsample.bn))
             if not hasattr(ops, "bn_apply2"):
                 identity = ops.bn_apply(*shortcut, None, False)
@@ -627,12 +638,74 @@ class NativeResNet:
                 out = self._unit_forward(u, out, None, True, train, p,
                                          colsum_for=b.units[last] if (i == last - 1 and last > 0) else None)
                 continue
+            if fuse_tail:
+                return self._fused_tail_forward(b, out, x)
             y, scale, shift = self._unit_conv_bn(u, out, train, p)
             tail = ("apply2", y, scale, shift, shortcut) if shortcut is not None else \
                 ("apply", y, scale, shift, identity)
             if self._can_slice(train) and self._n_slices(y) > 1 and b is not self.spec.blocks[-1]:
                 return tail                 # applied by the next block, slice by slice with its convs
             return self._apply_tail(tail, train)
+        return out
+
+    def _can_fuse_tail(self, b: BlockSpec, shape) -> bool:
+        """The block's tail (last 1x1 convolution + BatchNorm [+ projection shortcut + its BatchNorm] + add + ReLU)
+        runs as one kernel: a bottleneck block whose last unit -- and shortcut, if it has one -- will be folded in
+        backward (the two go together: without the convolution outputs there is nothing else backward could use)."""
+        if not self._fwd_fuse or len(b.units) < 2:
+            return False
+        u, d = b.units[-1], b.downsample
+        B, H, W, _ = shape
+        s = 1
+        for unit in b.units:
+            s *= unit.stride
+        Ho, Wo = H // s, W // s
+        nbytes = B * Ho * Wo * u.cout * torch.empty(0, dtype=self.dtype).element_size()
+        if not self._can_fold(u, nbytes):
+            return False
+        if d is None:
+            return s == 1
+        if d.stride == 1:
+            return s == 1 and self._can_fold(d, nbytes)
+        return d.stride == 2 and s == 2 and H % 2 == 0 and W % 2 == 0 and self._half_addend \
+            and self._can_fold(d, nbytes, strided=True)
+
+    def _fused_tail_forward(self, b: BlockSpec, a: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        """``relu(bn3(conv3(a)) + shortcut)`` without ``conv3(a)`` (or the projection's output) in memory.
+
+        ``y = a . W^T`` is a pointwise product, so ``sum_m y = W . colsum(a)`` and ``sum_m y^2 = W (a^T a) W^T``: the
+        batch statistics are known BEFORE the convolution runs.  BatchNorm's scale is folded into the weights, its
+        shift becomes the accumulators' start value, the identity is the epilogue's addend (a projection shortcut is
+        a second operand with its own folded weights), ReLU and the packed mask close the epilogue.  The Gram matrix
+        and column means are kept: they are what the folded backward of these units needs instead of ``y``."""
+        ops, P = self.ops, self.params
+        u, d = b.units[-1], b.downsample
+        Bn, H, W, _ = a.shape
+        rows = Bn * H * W
+
+        def unit_stats(unit: ConvBNSpec, inp: torch.Tensor, slot: Optional[str]) -> _UnitCtx:
+            gram, mom = ops.gram_and_means(inp, slot)
+            st = ops.bn_stats_from_gram(P.compute(f"{unit.conv}.weight"), gram, mom, rows, self.rm(unit.bn))
+            ctx = _UnitCtx()
+            ctx.x_in, ctx.gram, ctx.mom = inp, gram, mom
+            ctx.y_bytes = rows * unit.cout * inp.element_size()
+            self._bn_train(unit, ctx, st, rows)
+            self._ctx[unit.bn] = ctx
+            return ctx
+
+        slot = u.bn if self._saved.pop(f"colsum:{u.bn}", False) else None
+        self._colsum_pending.discard(u.bn)
+        ctx = unit_stats(u, a, slot)
+        w2 = sc2 = sh2 = xs = None
+        if d is not None:
+            xs = ops.subsample2(x) if d.stride == 2 else x          # the pixels the projection reads, dense
+            cd = unit_stats(d, xs, None)
+            w2, sc2, sh2 = P.compute(f"{d.conv}.weight"), cd.scale, cd.shift
+        wf, shift = ops.bn_fuse_fprop_weights(P.compute(f"{u.conv}.weight"), ctx.scale, ctx.shift, w2, sc2, sh2)
+        out = torch.empty(Bn, H, W, u.cout, dtype=a.dtype, device=a.device)
+        bits = self._new_bits(out, True)
+        ops.conv_fprop_fused_tail(a, wf, shift, addend=x if d is None else None, in2=xs, out=out,
+                                  **({"bits_out": bits} if bits is not None else {}))
         return out
 
     def _can_slice(self, train: bool) -> bool:
@@ -745,26 +818,34 @@ class NativeResNet:
         # (the deferred weight-gradient closures of the RCCL overlap mode are whole-layer units)
         return self._slice_bytes > 0 and not (self.sync_bn and self.syncbn_overlap and self._xgmi is None)
 
-    def _can_fold(self, u: ConvBNSpec, y: torch.Tensor, strided: bool = False) -> bool:
+    @staticmethod
+    def _ysize(ctx: _UnitCtx):
+        """The unit's output for :meth:`_can_fold`: the tensor, or its size when it was never materialised."""
+        return ctx.y if ctx.y is not None else ctx.y_bytes
+
+    def _can_fold(self, u: ConvBNSpec, y, strided: bool = False) -> bool:
         """The unit's BatchNorm backward is folded into its convolution's gradient products: a 1x1 / stride 1
         convolution with channel counts the kernels take (every bottleneck block's last unit) whose output
         ``y`` is large enough for the fold to pay.  ``strided``: a stride-2 one (a projection shortcut), for
         which the caller subsamples the input first."""
         if not self._bn_fold or u.ksize != 1 or u.stride != (2 if strided else 1) or u.pad != 0:
             return False
-        if y.numel() * y.element_size() < self._bn_fold_min_bytes:
+        nbytes = y if isinstance(y, int) else y.numel() * y.element_size()
+        if nbytes < self._bn_fold_min_bytes:
             return False
         if getattr(self.ops, "name", "") != "hip":
             return True
         return u.cin % 64 == 0 and u.cout % 64 == 0 and u.cin <= self.ops.BN_FOLD_MAX_C
 
-    def _folded_wgrad_fn(self, u: ConvBNSpec, x: torch.Tensor, g: torch.Tensor, fold, prod=None):
+    def _folded_wgrad_fn(self, u: ConvBNSpec, x: torch.Tensor, g: torch.Tensor, fold, prod=None, gram=None, mom=None):
         """Like :meth:`_conv_wgrad_fn`, for a unit whose BatchNorm backward is folded (``g`` is the gradient
         w.r.t. the BatchNorm output; ``prod``: the unscaled product ``g^T x`` when it exists already)."""
         P, ops, red = self.params, self.ops, self.reducer
         key = f"{u.conv}.weight"
         kw = {"prod": prod} if prod is not None else {}
-        if self._saved.pop(f"colsum:{u.bn}", False):
+        if gram is not None:
+            kw.update(gram=gram, mom=mom)           # kept from the forward pass (fused block tail)
+        elif self._saved.pop(f"colsum:{u.bn}", False):
             kw["amean_slot"] = u.bn                 # the forward pass left the column sums of x behind
             self._colsum_pending.discard(u.bn)
 
@@ -778,7 +859,7 @@ class NativeResNet:
                 ops.stream_wait_stream(ws.cuda_stream, cur, self._fork_event)
                 with torch.cuda.stream(ws):
                     ops.conv_wgrad_folded(x, g, fold, P.compute(key), P.grad(key), **kw)
-                self._wgrad_keep.append((x, g, prod, *fold.tensors()))   # must outlive the side-stream kernels
+                self._wgrad_keep.append((x, g, prod, gram, mom, *fold.tensors()))   # must outlive the side-stream kernels
                 if red.completes_bucket(end) and not self._reducer_waits_wgrad:
                     self._join_wgrad()
             self._mark_ready(end)
@@ -807,7 +888,7 @@ class NativeResNet:
             self._allreduce_bwd_sums(sums)
         fold = ops.bn_fold_prepare(sums, ctx.scale, ctx.invstd, ctx.mean, 1.0 / ctx.count, P.compute(key),
                                    self._wt_view(key))
-        self._wgrad(self._folded_wgrad_fn(u, ctx.x_in, g, fold, prod))
+        self._wgrad(self._folded_wgrad_fn(u, ctx.x_in, g, fold, prod, ctx.gram, ctx.mom))
         return ops.conv_dgrad_folded(g, ctx.x_in, fold,
                                      **((self._bstats(prev_u, MASK_RECOMPUTE) or {}) if prev_u is not None else {}))
 
@@ -865,7 +946,11 @@ class NativeResNet:
         for i in range(last, -1, -1):
             u = b.units[i]
             ctx = self._ctx.pop(u.bn)
-            if i == last and i > 0 and self._can_fold(u, ctx.y):
+            if i == last and i > 0 and (ctx.y is None or self._can_fold(u, ctx.y)):
+                if ctx.y is None and s0 is None:
+                    # a fused tail has no convolution output for the reduction pass over (g, y): s0 from g alone,
+                    # the rest from the weight-gradient product
+                    s0 = ops.channel_sums(cur)
                 cur = self._folded_tail_backward(u, b.units[i - 1], ctx, cur, g_prereduced, s0)
                 continue
             if i == last and i > 0 and self._can_slice_bwd() and self._n_slices(ctx.y) > 1:
@@ -890,7 +975,12 @@ class NativeResNet:
             d = b.downsample
             ctx = self._ctx.pop(d.bn)
             Bx, Hx, Wx, Cx = x_block.shape
-            if s0 is not None and self._can_fold(d, ctx.y):
+            if ctx.y is None:
+                # fused tail: the shortcut's input was subsampled in forward already
+                other = self._folded_tail_backward(d, None, ctx, g, False, s0)
+                dyd = None
+                half = d.stride == 2
+            elif s0 is not None and self._can_fold(d, ctx.y):
                 # (same g as the block's last BatchNorm: the same s0)
                 other = self._folded_tail_backward(d, None, ctx, g, False, s0)
                 dyd = None
@@ -924,7 +1014,8 @@ class NativeResNet:
         # where a zero means the whole pooling window was zero): apply its ReLU backward here.
         bits = getattr(x_block, "_pdt_relu_bits", None)
         mkw = {"relu_bits": bits} if bits is not None else {"relu_mask": x_block}
-        if prev_last is not None and self._bn_fold_product and self._can_fold(prev_last, self._ctx[prev_last.bn].y):
+        if prev_last is not None and self._bn_fold_product \
+                and self._can_fold(prev_last, self._ysize(self._ctx[prev_last.bn])):
             skw, pre = {"out_sums": True}, "s0"      # that unit is folded: all it wants with g is sum g
         else:
             # the fused backward sums of the previous block's last BatchNorm need the packed mask

@@ -23,6 +23,15 @@
 //   * bnfold_sums:     the backward sum s1 = sum g * xhat from T as well: sum_m g y = sum_c W[n][c] T[n][c], so the
 //                      kernel that produces g only has to add up g itself (s0) and does not read y either.
 //
+// The forward pass has the mirror image.  The batch statistics of y follow from the column sums and the Gram matrix
+// of a (the same G the backward wants):  sum_m y[m][n] = W[n] . colsum(a),  sum_m y[m][n]^2 = W[n] G W[n]^T  -- so
+// they are known BEFORE the convolution runs, BatchNorm's scale can be folded into the weights, and the block tail
+// relu(bn(y) + shortcut) becomes the convolution's epilogue: y is not written in forward either.
+//
+//   * bnfold_fwd_stats:      the shifted sums [sum (y - s), sum (y - s)^2] in the accumulator format of the other
+//                            statistics kernels (reduce.hip), from W, G and colsum(a);
+//   * bnfold_scale_weights:  rows of [scale o W | scale2 o W2] and the summed shifts.
+//
 // Both multiply on the matrix cores (v_mfma_f32_32x32x16_bf16, operands straight from global memory: the matrices
 // are a few hundred rows, launch latency is what counts).  G holds sums over ~10^6 pixels, so its bf16 operand is
 // split into a high and a low part (two MFMAs, 16 mantissa bits).
@@ -241,5 +250,123 @@ PDT_API int pdt_bnfold_sums(const float* prod, const void* w, const float* s0, c
     if (C < 8 || C % 8 != 0 || N < 1) return -4;
     hipLaunchKernelGGL(bnfold_sums_kernel, dim3((N + 3) / 4), dim3(256), 0, s, prod, (const bf16*)w, s0, mean, invstd, sums,
                        dgamma, dbeta, C, N);
+    return pdt_launch_status();
+}
+
+// acc row 0: sum_m (y - s) = W[n].cs - rows s_n ;  sum_m (y - s)^2 = W[n] G W[n]^T - 2 s_n W[n].cs + rows s_n^2
+// (y = a W^T, cs = colsum(a) = rows * amean, G = a^T a).  One block per 32 channels n; its four waves split the
+// 32-column tiles of W.G, each element of which is multiplied by W[n][c] and added up over c.
+__global__ __launch_bounds__(256) void bnfold_fwd_stats_kernel(const bf16* __restrict__ w, const float* __restrict__ gram,
+                                                                const float* __restrict__ amean, float rows,
+                                                                const float* __restrict__ shift,
+                                                                float* __restrict__ acc, int C, int N) {
+    __shared__ float red[2][4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    float q[16];                                   // partial sum_c (W.G)[n][c] W[n][c] for this lane's 16 rows
+#pragma unroll
+    for (int i = 0; i < 16; ++i) q[i] = 0.f;
+    const bf16* pa = w + (size_t)(n0 + r) * C + 8 * h;
+    for (int ct = wave; ct < C / 32; ct += 4) {
+        const float* pg = gram + (size_t)(32 * ct + r) * C + 8 * h;          // G[c][c'] stands in for G[c'][c]
+        f32x16 t;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = 0.f;
+#pragma unroll 4
+        for (int s = 0; s < C / 16; ++s) {
+            const bf16x8 av = *reinterpret_cast<const bf16x8*>(pa + 16 * s);
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(pg + 16 * s);
+            const f32x4 g1 = *reinterpret_cast<const f32x4*>(pg + 16 * s + 4);
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                hi[k] = f2bf(g0[k]);
+                lo[k] = f2bf(g0[k] - bf2f(hi[k]));
+                hi[4 + k] = f2bf(g1[k]);
+                lo[4 + k] = f2bf(g1[k] - bf2f(hi[4 + k]));
+            }
+            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, hi, t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, lo, t, 0, 0, 0);
+        }
+        // t[reg]: row (reg & 3) + 8 (reg >> 2) + 4 h, column c = 32 ct + r
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            q[i] += t[i] * bf2f(w[(size_t)(n0 + row) * C + 32 * ct + r]);
+        }
+    }
+    // sum over the 32 columns held by the lanes of each half, then over the waves
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float v = q[i];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        q[i] = v;
+    }
+    if (r == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[0][wave][(i & 3) + 8 * (i >> 2) + 4 * h] = q[i];
+    }
+    // W[n] . amean: thread (row = tid / 8, part = tid % 8)
+    {
+        const int row = tid >> 3, part = tid & 7;
+        float d = 0.f;
+        for (int c = part; c < C; c += 8) d += bf2f(w[(size_t)(n0 + row) * C + c]) * amean[c];
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        d += __shfl_xor(d, 4, 64);
+        if (part == 0) red[1][0][row] = d;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const int n = n0 + tid;
+        const float quad = red[0][0][tid] + red[0][1][tid] + red[0][2][tid] + red[0][3][tid];
+        const float lin = red[1][0][tid] * rows;          // sum_m y
+        const float sh = shift ? shift[n] : 0.f;
+        acc[n] = lin - rows * sh;
+        acc[N + n] = quad - 2.f * sh * lin + rows * sh * sh;
+    }
+}
+
+// acc: the [nrep][2][N] accumulator of the statistics kernels (row 0 is written, the others stay zero)
+PDT_API int pdt_bnfold_fwd_stats(const void* w, const float* gram, const float* amean, float rows, const float* shift,
+                                 float* acc, int C, int N, hipStream_t s) {
+    if (C < 32 || C % 32 != 0 || N < 32 || N % 32 != 0) return -4;
+    hipLaunchKernelGGL(bnfold_fwd_stats_kernel, dim3(N / 32), dim3(256), 0, s, (const bf16*)w, gram, amean, rows, shift, acc,
+                       C, N);
+    return pdt_launch_status();
+}
+
+// wf[n][0..C) = scale[n] w[n][:],  wf[n][C..C+C2) = scale2[n] w2[n][:]  (second part optional);  shift_out = shift (+ shift2)
+__global__ __launch_bounds__(256) void bnfold_scale_weights_kernel(const bf16* __restrict__ w, const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift,
+                                                                    const bf16* __restrict__ w2,
+                                                                    const float* __restrict__ scale2,
+                                                                    const float* __restrict__ shift2,
+                                                                    bf16* __restrict__ wf, float* __restrict__ shift_out,
+                                                                    int C, int C2, int N) {
+    const int n = blockIdx.x;
+    const int ld = C + C2;
+    const float sc = scale[n], sc2 = w2 ? scale2[n] : 0.f;
+    for (int c = threadIdx.x * 8; c < ld; c += 256 * 8) {
+        const bool second = c >= C;
+        const bf16x8 v = second ? *reinterpret_cast<const bf16x8*>(w2 + (size_t)n * C2 + (c - C))
+                                : *reinterpret_cast<const bf16x8*>(w + (size_t)n * C + c);
+        const float f = second ? sc2 : sc;
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = f2bf(bf2f(v[k]) * f);
+        *reinterpret_cast<bf16x8*>(wf + (size_t)n * ld + c) = o;
+    }
+    if (threadIdx.x == 0) shift_out[n] = shift[n] + (w2 ? shift2[n] : 0.f);
+}
+
+PDT_API int pdt_bnfold_scale_weights(const void* w, const float* scale, const float* shift, const void* w2,
+                                     const float* scale2, const float* shift2, void* wf, float* shift_out, int C, int C2,
+                                     int N, hipStream_t s) {
+    if (C % 8 != 0 || C2 % 8 != 0 || N < 1 || (w2 == nullptr) != (C2 == 0)) return -4;
+    hipLaunchKernelGGL(bnfold_scale_weights_kernel, dim3(N), dim3(256), 0, s, (const bf16*)w, scale, shift, (const bf16*)w2,
+                       scale2, shift2, (bf16*)wf, shift_out, C, C2, N);
     return pdt_launch_status();
 }

@@ -38,7 +38,9 @@
 // may start from a per-output-channel constant instead of zero.  Together they evaluate
 //   out = in . W1^T + in2 . W2^T + bias
 // in one pass, which is how a BatchNorm backward is folded into the data gradient of the 1x1 convolution
-// in front of it (bn_fold.hip): no normalised-gradient tensor is ever written.
+// in front of it (bn_fold.hip): no normalised-gradient tensor is ever written.  The same instantiations can clamp
+// the result at zero and write its packed sign mask: with BatchNorm's scale folded into the weights and its shift
+// as start value, a block tail  relu(bn(conv(a)) [+ bn(conv_shortcut(x))] [+ x])  is this kernel's epilogue.
 #include "common.h"
 
 #define DMA_MAX_TAPS 52
@@ -66,7 +68,9 @@ struct ConvDmaParams {
     int addend_half;                   // addend is [B][Ho/2][Wo/2][N], present at even output (y, x) only
     int nrep;                          // replica rows of the statistics accumulator (see common.h)
     const bf16* in2;                   // second operand [M][pix_stride2] (may be null), reduced after the taps
-    const float* bias;                 // [N] start value of the accumulators (may be null; N <= DMA_MAX_BIAS)
+    const float* bias;                 // [N] start value of the accumulators (may be null)
+    unsigned char* bits_out;           // packed [out > 0] of the stored result, one bit per element (may be null)
+    int relu_out;                      // clamp the result at zero before it is stored
     unsigned in2_bytes;
     int Ci2, pix_stride2;
     int taps[DMA_MAX_TAPS];            // offy (int8) | offx (int8) << 8 | widx (uint16) << 16
@@ -329,7 +333,8 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
         for (int i = tid; i < p.N; i += 256) bias_lds[i] = p.bias[i];
         __syncthreads();
     };
-    if (has_bias) stage_bias();
+    const bool bias_in_lds = has_bias && p.N <= DMA_MAX_BIAS;      // wider layers read their 16 values per tile from memory
+    if (bias_in_lds) stage_bias();
     setup_issue_tile();
     bool issuing = true;
 #pragma unroll
@@ -342,8 +347,9 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             // accumulator register r of lane group fq: channel n0 + wn*WTN + j*16 + fq*4 + r
-            const f32x4 b0 = has_bias ? *reinterpret_cast<const f32x4*>(bias_lds + n0 + wn * WTN + j * 16 + fq * 4)
-                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (bias_in_lds) b0 = *reinterpret_cast<const f32x4*>(bias_lds + n0 + wn * WTN + j * 16 + fq * 4);
+            else if (has_bias) b0 = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * WTN + j * 16 + fq * 4);
 #pragma unroll
             for (int i = 0; i < MI; ++i) acc[i][j] = b0;
         }
@@ -368,7 +374,8 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
         if (want_stats && stat_n0 != n0) {
             if (stat_n0 >= 0) {
                 flush_stats(stat_n0);
-                if (has_bias) stage_bias();
+                const bool bias_in_lds = has_bias && p.N <= DMA_MAX_BIAS;      // wider layers read their 16 values per tile from memory
+    if (bias_in_lds) stage_bias();
             }
             stat_n0 = n0;
             load_consts(nb);
@@ -459,6 +466,16 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
             if (has_mask) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) val[k] = ((mb[e] >> k) & 1u) ? val[k] : 0.0f;
+            }
+            if (FOLD && !BSTAT && p.relu_out) {              // (forward tails only: no backward-sums epilogue there)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) val[k] = fmaxf(val[k], 0.0f);
+            }
+            if (FOLD && !BSTAT && p.bits_out && live[e]) {
+                unsigned m16 = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) m16 |= (val[k] > 0.0f ? 1u : 0u) << k;
+                *reinterpret_cast<unsigned short*>(p.bits_out + (oidx[e] >> 3)) = (unsigned short)m16;
             }
             if (live[e]) {
                 u32x4 o0, o1;
@@ -551,7 +568,7 @@ PDT_API int pdt_conv_dma_ex(const void* in, const void* wgt, void* out, const vo
                             int Wi, int pix_stride, int Ci, int Hg, int Wg, int IS, int Ho, int Wo, int OS, int oy0, int ox0,
                             int N, int wrow, int T, const signed char* offy, const signed char* offx,
                             const unsigned short* widx, int tile, const void* in2, int Ci2, int pix_stride2,
-                            const float* bias, hipStream_t s) {
+                            const float* bias, int relu_out, void* bits_out, hipStream_t s) {
     if (T <= 0 || T > DMA_MAX_TAPS) return -3;
     if (M <= 0) return 0;
     if (!in2) Ci2 = 0;
@@ -562,7 +579,7 @@ PDT_API int pdt_conv_dma_ex(const void* in, const void* wgt, void* out, const vo
         if (Ci2 < 64 || Ci2 % 64 != 0 || pix_stride2 < Ci2 || pix_stride2 % 8 != 0) return -11;
         if (M * (long long)pix_stride2 * 2 >= 0x7fff0000LL) return -7;
     }
-    if (bias && N > DMA_MAX_BIAS) return -12;
+    if ((relu_out || bits_out) && (!(in2 || bias) || bstat_y)) return -12;   // forward instantiations with a second operand / start values only
     if (tile == 5) {
         // K slices of 32 over a gathered operand whose "pixels" may overlap (the stem reads 32 consecutive values of its
         // packed NHWC4 image per tap: pix_stride 4, Ci 32): every DMA source address must still be 16-byte aligned
@@ -589,6 +606,7 @@ PDT_API int pdt_conv_dma_ex(const void* in, const void* wgt, void* out, const vo
     p.addend_half = (addend && addend_half) ? 1 : 0;
     p.nrep = pdt_nrep();
     p.in2 = (const bf16*)in2; p.bias = bias; p.Ci2 = Ci2; p.pix_stride2 = in2 ? pix_stride2 : 0;
+    p.relu_out = relu_out ? 1 : 0; p.bits_out = (unsigned char*)bits_out;
     p.in2_bytes = in2 ? (unsigned)(M * (long long)pix_stride2 * 2) : 0u;
     {
         long long images = M / ((long long)Hg * Wg);
@@ -628,5 +646,5 @@ PDT_API int pdt_conv_dma(const void* in, const void* wgt, void* out, const void*
                          const unsigned short* widx, int tile, hipStream_t s) {
     return pdt_conv_dma_ex(in, wgt, out, addend, addend_half, mask_bits, stat_acc, stat_shift, bstat_y, bstat_mean,
                            bstat_scale, bstat_shift, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, wrow,
-                           T, offy, offx, widx, tile, nullptr, 0, 0, nullptr, s);
+                           T, offy, offx, widx, tile, nullptr, 0, 0, nullptr, 0, nullptr, s);
 }

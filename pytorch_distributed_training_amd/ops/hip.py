@@ -84,7 +84,9 @@ _sig("pdt_conv_wgrad", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _
 _sig("pdt_conv_wgrad_ex", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _ll,
      _vp, _vp)
 _sig("pdt_conv_dma_ex", _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-     _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp)
+     _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp)
+_sig("pdt_bnfold_fwd_stats", _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp)
+_sig("pdt_bnfold_scale_weights", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp)
 _sig("pdt_bnfold_prepare", _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp)
 _sig("pdt_bnfold_wgrad", _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp)
 _sig("pdt_bnfold_sums", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp)
@@ -978,18 +980,126 @@ def conv_dgrad_folded(g: torch.Tensor, a_in: torch.Tensor, fold: BnFold, bwd_sta
         rc = _lib.pdt_conv_dma_ex(_p(g[b0:b1]), _p(fold.wfold), _p(dx[b0:b1]), None, 0, None, _p(acc), None,
                                   _p(by[b0:b1]) if by is not None else None, _p(bmean), _p(bscale), _p(bshift), M, H, W, N,
                                   N, H, W, 1, H, W, 1, 0, 0, C, N + C, 1, taps.offy, taps.offx, taps.widx, tile,
-                                  _p(a_in[b0:b1]), C, C, _p(fold.bias), _stream())
+                                  _p(a_in[b0:b1]), C, C, _p(fold.bias), 0, None, _stream())
         _check(rc, "pdt_conv_dma_ex")
     return dx
 
 
+def gram_and_means(a: torch.Tensor, colsum_slot: Optional[str] = None):
+    """``(G, mom)`` of an NHWC tensor seen as ``[rows, C]``: the Gram matrix ``a^T a`` (``[C, C]`` fp32, an ordinary
+    weight-gradient launch with ``a`` on both sides) and ``mom[0]`` = the column means (``mom[1]``: scratch).
+    ``colsum_slot``: the column sums were left in that accumulator by ``bn_apply(colsum_slot=...)``."""
+    a = _bf16c(a, "gram_and_means")
+    B, H, W, C = a.shape
+    rows = B * H * W
+    dev = a.device
+    if colsum_slot and not _deterministic:
+        acc = _accumulator(dev, C, "colsum:" + colsum_slot)
+    else:
+        acc = _accumulator(dev, C, "fold")
+        _check(_lib.pdt_bn_stats_accum(_p(a), None, _p(acc), rows, C, _stream()), "pdt_bn_stats_accum")
+    mom = torch.empty(2, C, dtype=torch.float32, device=dev)
+    _check(_lib.pdt_bn_moments(_p(acc), _p(mom), C, 1.0 / rows, _stream()), "pdt_bn_moments")
+    gram = torch.empty(C, C, dtype=torch.float32, device=dev)
+    _check(_lib.pdt_zero_f32(_p(gram), C * C, _stream()), "pdt_zero_f32")
+    _wgrad(a, a, gram, rows, H, W, C, C, H, W, 1, C, C, C, _one_tap())
+    return gram, mom
+
+
+def bn_stats_from_gram(w: torch.Tensor, gram: torch.Tensor, mom: torch.Tensor, rows: int,
+                       stat_shift: Optional[torch.Tensor], acc_slot: str = "stats") -> "PendingStats":
+    """Batch statistics of ``y = a . w^T`` (1x1 convolution, ``w``: ``[N, 1, 1, C]``) WITHOUT ``y``: from the Gram
+    matrix and column means of ``a`` (:func:`gram_and_means`).  Returns what ``conv_fprop(defer_stats=True)`` would:
+    the shifted sums in the accumulator, to be consumed by :func:`bn_finalize_fused` / :func:`stats_to_moments`."""
+    w = _bf16c(w, "bn_stats_from_gram w")
+    N, C = w.shape[0], w.shape[-1]
+    if w.numel() != N * C or C % 32 or N % 32 or tuple(gram.shape) != (C, C):
+        raise ValueError("bn_stats_from_gram: needs a 1x1 filter with channel counts in multiples of 32")
+    acc = _accumulator(w.device, N, acc_slot)
+    rc = _lib.pdt_bnfold_fwd_stats(_p(w), _p(_f32c(gram, "gram")), _p(mom), float(rows), _p(stat_shift), _p(acc), C, N,
+                                   _stream())
+    _check(rc, "pdt_bnfold_fwd_stats")
+    return PendingStats(acc, N, rows)
+
+
+def bn_fuse_fprop_weights(w, scale, shift, w2=None, scale2=None, shift2=None):
+    """``([scale o w | scale2 o w2], shift + shift2)``: the weights and accumulator start values with which
+    ``conv(a, .) [+ conv(x, .)]`` IS ``bn(conv(a, w)) [+ bn2(conv(x, w2))]`` (``w2`` optional; both 1x1)."""
+    w = _bf16c(w, "bn_fuse_fprop_weights w")
+    N, C = w.shape[0], w.shape[-1]
+    C2 = 0
+    if w2 is not None:
+        w2 = _bf16c(w2, "bn_fuse_fprop_weights w2")
+        C2 = w2.shape[-1]
+        if w2.shape[0] != N or w2.numel() != N * C2:
+            raise ValueError("bn_fuse_fprop_weights: the two filters must have the same output channels")
+    if w.numel() != N * C:
+        raise ValueError("bn_fuse_fprop_weights: 1x1 filters only")
+    wf = torch.empty(N, C + C2, dtype=torch.bfloat16, device=w.device)
+    sh = torch.empty(N, dtype=torch.float32, device=w.device)
+    rc = _lib.pdt_bnfold_scale_weights(_p(w), _p(scale), _p(shift), _p(w2), _p(scale2), _p(shift2), _p(wf), _p(sh), C, C2,
+                                       N, _stream())
+    _check(rc, "pdt_bnfold_scale_weights")
+    return wf, sh
+
+
+def conv_fprop_fused_tail(a: torch.Tensor, wf: torch.Tensor, shift: torch.Tensor, addend: Optional[torch.Tensor] = None,
+                          in2: Optional[torch.Tensor] = None, bits_out: Optional[torch.Tensor] = None,
+                          out: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
+    """``relu(a . wf[:, :C]^T + in2 . wf[:, C:]^T + shift + addend)`` in one kernel: with the weights of
+    :func:`bn_fuse_fprop_weights` the whole tail of a residual block (1x1 convolution, BatchNorm, projection or
+    identity shortcut, ReLU, packed ReLU mask) without the convolution outputs in memory."""
+    a = _bf16c(a, "conv_fprop_fused_tail a")
+    wf = _bf16c(wf, "conv_fprop_fused_tail wf")
+    B, H, W, C = a.shape
+    N = wf.shape[0]
+    C2 = wf.shape[1] - C
+    if (in2 is None) != (C2 == 0) or C % 64 or N % 64 or C2 % 64:
+        raise ValueError("conv_fprop_fused_tail: weight columns do not match the operands")
+    if in2 is not None:
+        in2 = _bf16c(in2, "conv_fprop_fused_tail in2")
+        if tuple(in2.shape) != (B, H, W, C2):
+            raise ValueError("conv_fprop_fused_tail: the second operand must have the first one's pixels")
+    y = _out_like(out, (B, H, W, N), a.device, "conv_fprop_fused_tail")
+    if addend is not None:
+        addend = _bf16c(addend, "conv_fprop_fused_tail addend")
+        if tuple(addend.shape) != (B, H, W, N):
+            raise ValueError("conv_fprop_fused_tail: addend shape")
+    if bits_out is not None:
+        _check_bits(bits_out, (B, H, W, N), "conv_fprop_fused_tail bits_out")
+    taps = _one_tap()
+    parts = _batch_parts(B, max(y.numel(), a.numel()) * 2) or [(0, B)]
+    for b0, b1 in parts:
+        M = (b1 - b0) * H * W
+        rc = _lib.pdt_conv_dma_ex(_p(a[b0:b1]), _p(wf), _p(y[b0:b1]), _p(_part(addend, b0, b1)), 0, None, None, None, None,
+                                  None, None, None, M, H, W, C, C, H, W, 1, H, W, 1, 0, 0, N, C + C2, 1, taps.offy,
+                                  taps.offx, taps.widx, tile, _p(_part(in2, b0, b1)), C2, C2, _p(shift), 1,
+                                  _p(_part(bits_out, b0, b1)), _stream())
+        _check(rc, "pdt_conv_dma_ex")
+    return y
+
+
+def channel_sums(g: torch.Tensor) -> torch.Tensor:
+    """``[C]`` per-channel sums of an NHWC tensor."""
+    g = _bf16c(g, "channel_sums")
+    C = g.shape[-1]
+    rows = g.numel() // C
+    acc = _accumulator(g.device, C, "fold")
+    _check(_lib.pdt_bn_stats_accum(_p(g), None, _p(acc), rows, C, _stream()), "pdt_bn_stats_accum")
+    out = torch.empty(2, C, dtype=torch.float32, device=g.device)
+    _check(_lib.pdt_bn_moments(_p(acc), _p(out), C, 1.0, _stream()), "pdt_bn_moments")
+    return out[0]
+
+
 def conv_wgrad_folded(a_in: torch.Tensor, g: torch.Tensor, fold: BnFold, w: torch.Tensor, dw: torch.Tensor,
-                      prod: Optional[torch.Tensor] = None, amean_slot: Optional[str] = None) -> None:
+                      prod: Optional[torch.Tensor] = None, amean_slot: Optional[str] = None, gram=None,
+                      mom=None) -> None:
     """``dw += (A o g + B o y + K)^T . a_in`` without the tensor in parentheses and without ``y``: the scaled
     product ``A o (g^T a)``, the Gram matrix ``a^T a`` (an ordinary weight-gradient launch with ``a`` on both
     sides), the column means of ``a``, and the small correction kernel.  ``prod``: the unscaled ``g^T a`` is
     already there (see :func:`bn_fold_sums`); the correction kernel scales and adds it.  ``amean_slot``: the
-    column sums of ``a_in`` were left in that accumulator by ``bn_apply(colsum_slot=...)``."""
+    column sums of ``a_in`` were left in that accumulator by ``bn_apply(colsum_slot=...)``.  ``gram`` / ``mom``:
+    the Gram matrix and column means exist already (:func:`gram_and_means`, e.g. from the forward pass)."""
     if _ABLATE_WGRAD:
         return
     a_in = _bf16c(a_in, "conv_wgrad_folded a_in")
@@ -1003,18 +1113,8 @@ def conv_wgrad_folded(a_in: torch.Tensor, g: torch.Tensor, fold: BnFold, w: torc
     rows = B * H * W
     dev = a_in.device
     taps = _one_tap()
-    # column means of a
-    if amean_slot and not _deterministic:
-        acc = _accumulator(dev, C, "colsum:" + amean_slot)
-    else:
-        acc = _accumulator(dev, C, "fold")
-        _check(_lib.pdt_bn_stats_accum(_p(a_in), None, _p(acc), rows, C, _stream()), "pdt_bn_stats_accum")
-    mom = torch.empty(2, C, dtype=torch.float32, device=dev)
-    _check(_lib.pdt_bn_moments(_p(acc), _p(mom), C, 1.0 / rows, _stream()), "pdt_bn_moments")
-    # G = a^T a
-    gram = torch.empty(C, C, dtype=torch.float32, device=dev)
-    _check(_lib.pdt_zero_f32(_p(gram), C * C, _stream()), "pdt_zero_f32")
-    _wgrad(a_in, a_in, gram, rows, H, W, C, C, H, W, 1, C, C, C, taps)
+    if gram is None or mom is None:
+        gram, mom = gram_and_means(a_in, amean_slot)
     if prod is None:
         # A o (g^T a) straight into the gradient buffer, then the correction
         _wgrad(g, a_in, dw, rows, H, W, C, C, H, W, 1, N, N, C, taps, row_scale=fold.coef[0])

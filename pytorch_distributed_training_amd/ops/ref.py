@@ -384,8 +384,66 @@ def conv_dgrad_folded(g: torch.Tensor, a_in: torch.Tensor, fold: BnFold, bwd_sta
     return dx
 
 
+def gram_and_means(a: torch.Tensor, colsum_slot: Optional[str] = None):
+    """``(a^T a, [column means, column means of squares])`` of an NHWC tensor seen as ``[rows, C]`` (fp32)."""
+    a2 = a.float().reshape(-1, a.shape[-1])
+    return a2.t() @ a2, torch.stack([a2.mean(0), (a2 * a2).mean(0)])
+
+
+def bn_stats_from_gram(w: torch.Tensor, gram: torch.Tensor, mom: torch.Tensor, rows: int,
+                       stat_shift: Optional[torch.Tensor], **_) -> torch.Tensor:
+    """Shifted moments (see :func:`channel_moments`) of ``y = a . w^T`` from the Gram matrix and column means of
+    ``a`` alone: ``E[y_n] = w_n . mean(a)``, ``E[y_n^2] = w_n (a^T a / rows) w_n^T`` -- the batch statistics of a
+    1x1 convolution's output are known before the convolution has run."""
+    N, C = w.shape[0], w.shape[-1]
+    w2 = w.reshape(N, C).float()
+    mean = w2 @ mom[0]
+    ey2 = ((w2 @ (gram / rows)) * w2).sum(1)
+    s = stat_shift if stat_shift is not None else torch.zeros_like(mean)
+    return torch.stack([mean - s, ey2 - 2 * s * mean + s * s])
+
+
+def bn_fuse_fprop_weights(w, scale, shift, w2=None, scale2=None, shift2=None):
+    """``([scale o w | scale2 o w2], shift + shift2)`` (rows = output channels; ``w2`` optional, both 1x1)."""
+    N = w.shape[0]
+    parts = [w.reshape(N, -1).float() * scale[:, None]]
+    sh = shift.clone()
+    if w2 is not None:
+        parts.append(w2.reshape(N, -1).float() * scale2[:, None])
+        sh = sh + shift2
+    return torch.cat(parts, dim=1).to(w.dtype).contiguous(), sh
+
+
+def conv_fprop_fused_tail(a: torch.Tensor, wf: torch.Tensor, shift: torch.Tensor, addend: Optional[torch.Tensor] = None,
+                          in2: Optional[torch.Tensor] = None, bits_out: Optional[torch.Tensor] = None,
+                          out: Optional[torch.Tensor] = None, **_) -> torch.Tensor:
+    """``relu(a . wf[:, :C]^T + in2 . wf[:, C:]^T + shift + addend)`` (+ packed sign mask): a residual block's tail
+    as one product, see :func:`bn_fuse_fprop_weights`."""
+    C = a.shape[-1]
+    N = wf.shape[0]
+    wf32 = wf.float()
+    y = a.float().reshape(-1, C) @ wf32[:, :C].t() + shift
+    if in2 is not None:
+        y = y + in2.float().reshape(-1, in2.shape[-1]) @ wf32[:, C:].t()
+    y = y.reshape(*a.shape[:-1], N)
+    if addend is not None:
+        y = y + addend.float()
+    y = torch.relu(y).to(a.dtype)
+    if bits_out is not None:
+        _pack_bits(y, bits_out)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def channel_sums(g: torch.Tensor) -> torch.Tensor:
+    return g.float().reshape(-1, g.shape[-1]).sum(0)
+
+
 def conv_wgrad_folded(a_in: torch.Tensor, g: torch.Tensor, fold: BnFold, w: torch.Tensor, dw: torch.Tensor,
-                      prod: Optional[torch.Tensor] = None, amean_slot: Optional[str] = None) -> None:
+                      prod: Optional[torch.Tensor] = None, amean_slot: Optional[str] = None, gram=None,
+                      mom=None) -> None:
     """``dw += A o (g^T a) + B o (w . (a^T a)) + K (x) colsum(a)`` (see :func:`bn_fold_prepare`); ``prod``: the
     product ``g^T a`` when it has been formed already (:func:`bn_fold_sums`)."""
     N, C = fold.N, fold.C

@@ -113,13 +113,13 @@ def _fold_worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
     x, y = _data()
     out = {}
-    for fold in ("1", "0"):
-        os.environ["PDT_BN_FOLD"] = fold
+    for tag, fold, fwd in (("F", "1", "1"), ("1", "1", "0"), ("0", "0", "0")):
+        os.environ["PDT_BN_FOLD"], os.environ["PDT_FWD_FUSE"] = fold, fwd
         eng = _engine(True, model="ResNet50")
-        assert eng._bn_fold == (fold == "1") and eng._bn_fold_product == (fold == "1")
+        assert eng._bn_fold == (fold == "1") and eng._bn_fold_product == (fold == "1") and eng._fwd_fuse == (fwd == "1")
         eng.broadcast_state(0)
-        out["loss" + fold] = eng.forward_backward(x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4])
-        out["grads" + fold] = eng.params.g.clone() * eng.reducer.grad_scale
+        out["loss" + tag] = eng.forward_backward(x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4])
+        out["grads" + tag] = eng.params.g.clone() * eng.reducer.grad_scale
     torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
@@ -130,15 +130,19 @@ def test_syncbn_with_folded_batchnorm_backward(tmp_path):
     every folded unit are all-reduced.  Compared with the SAME two-rank run without the fold: the forward passes
     are identical, so what differs is backward rounding only.  (Against ONE process on the concatenated batch the
     gradients of this 53-BatchNorm network agree to about a per cent with or without the fold: at 8 samples its
-    forward pass amplifies a 1e-7 change of the input into 1e-2 of the gradient.)"""
+    forward pass amplifies a 1e-7 change of the input into 1e-2 of the gradient.)  Third variant: block tails fused
+    in forward as well (statistics from the Gram matrix, exchanged like any other) -- another rounding of the
+    forward pass, hence compared by loss and direction."""
     port = _free_port()
     mp.spawn(_fold_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
-    for fold in ("1", "0"):
-        assert torch.equal(r0["grads" + fold], r1["grads" + fold])          # replicas agree bit for bit
+    for tag in ("F", "1", "0"):
+        assert torch.equal(r0["grads" + tag], r1["grads" + tag])            # replicas agree bit for bit
     assert r0["loss1"].item() == r0["loss0"].item()
     err = (r0["grads1"] - r0["grads0"]).norm() / r0["grads0"].norm()
     assert err.item() < 1e-4, err.item()
+    assert r0["lossF"].item() == pytest.approx(r0["loss0"].item(), rel=1e-3)
+    assert torch.nn.functional.cosine_similarity(r0["gradsF"], r0["grads0"], dim=0).item() > 0.99
 
 
 def _trainer_cfg(tmp_path, extra=None):
