@@ -374,8 +374,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
         if (want_stats && stat_n0 != n0) {
             if (stat_n0 >= 0) {
                 flush_stats(stat_n0);
-                const bool bias_in_lds = has_bias && p.N <= DMA_MAX_BIAS;      // wider layers read their 16 values per tile from memory
-    if (bias_in_lds) stage_bias();
+                if (bias_in_lds) stage_bias();
             }
             stat_n0 = n0;
             load_consts(nb);
