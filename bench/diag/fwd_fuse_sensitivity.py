@@ -1,6 +1,7 @@
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 os.environ["PDT_BN_FOLD_MIN_MB"] = "0"
+os.environ["PDT_BN_FOLD_MAX_COUT"] = "0"
 from pytorch_distributed_training_amd.engine.native_resnet import NativeResNet
 from pytorch_distributed_training_amd.models import get_model, get_spec
 from pytorch_distributed_training_amd.ops import hip

@@ -198,6 +198,10 @@ class NativeResNet:
         # gradients) and loses on the 7x7 stage (103 MB).
         self._bn_fold_min_bytes = int(float(os.environ.get("PDT_BN_FOLD_MIN_MB", "150")) * 2 ** 20) \
             if self.device.type == "cuda" else 0
+        # ... and where it is not too wide: per byte avoided, the extra multiplies (Gram matrix, second operand) grow
+        # with the channel count.  The 7x7 stage (2048 channels) loses at any batch: 61.75 ms/step folded against
+        # 61.47 at batch 1024, where its tensors are as large as the 14x14 stage's at 512.  (0: no limit.)
+        self._bn_fold_max_cout = int(os.environ.get("PDT_BN_FOLD_MAX_COUT", "1024")) if self.device.type == "cuda" else 0
         # Folded units take their backward sum s1 from the (unscaled) weight-gradient product, so the kernel that
         # produces their incoming gradient only adds up the gradient itself and reads no BatchNorm input for them;
         # with that, a stride-1 projection shortcut is folded as well (PDT_BN_FOLD_PRODUCT=0: sums as before).
@@ -553,13 +557,7 @@ class NativeResNet:
     def _will_fold(self, u: ConvBNSpec, x_in: torch.Tensor) -> bool:
         """:meth:`_can_fold` before the unit has run: from its input (1x1 / stride 1: the output has the input's
         pixels and ``u.cout`` channels)."""
-        if not self._bn_fold or u.ksize != 1 or u.stride != 1 or u.pad != 0:
-            return False
-        if (x_in.numel() // x_in.shape[-1]) * u.cout * x_in.element_size() < self._bn_fold_min_bytes:
-            return False
-        if getattr(self.ops, "name", "") != "hip":
-            return True
-        return u.cin % 64 == 0 and u.cout % 64 == 0 and u.cin <= self.ops.BN_FOLD_MAX_C
+        return self._can_fold(u, (x_in.numel() // x_in.shape[-1]) * u.cout * x_in.element_size())
 
     # -- cache-sized batch slices ---------------------------------------------------------------
     def _n_slices(self, t: torch.Tensor) -> int:
@@ -831,7 +829,7 @@ class NativeResNet:
         if not self._bn_fold or u.ksize != 1 or u.stride != (2 if strided else 1) or u.pad != 0:
             return False
         nbytes = y if isinstance(y, int) else y.numel() * y.element_size()
-        if nbytes < self._bn_fold_min_bytes:
+        if nbytes < self._bn_fold_min_bytes or (self._bn_fold_max_cout and u.cout > self._bn_fold_max_cout):
             return False
         if getattr(self.ops, "name", "") != "hip":
             return True

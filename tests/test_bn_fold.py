@@ -310,6 +310,7 @@ def test_hip_engine_with_and_without_the_folded_path(hip, device, monkeypatch):
     label = torch.randint(0, 10, (8,), device=device)
     grads, losses = [], []
     monkeypatch.setenv("PDT_BN_FOLD_MIN_MB", "0")        # fold every bottleneck block, however small its tensors
+    monkeypatch.setenv("PDT_BN_FOLD_MAX_COUT", "0")      # ... and however wide
     for on, product, fwd in (("1", "1", "1"), ("1", "1", "0"), ("1", "0", "0"), ("0", "0", "0")):
         monkeypatch.setenv("PDT_BN_FOLD", on)
         monkeypatch.setenv("PDT_BN_FOLD_PRODUCT", product)

@@ -64,6 +64,7 @@ def test_two_deterministic_runs_with_every_batchnorm_backward_folded(device, mon
     """The folded BatchNorm backward (forced onto every bottleneck block, however small) keeps the guarantee: its
     products go through the slab weight gradient, its small kernels have one writer per element."""
     monkeypatch.setenv("PDT_BN_FOLD_MIN_MB", "0")
+    monkeypatch.setenv("PDT_BN_FOLD_MAX_COUT", "0")
     p1, rm1, rv1, l1, _ = _run(device, True)
     p2, rm2, rv2, l2, _ = _run(device, True)
     assert l1 == l2, (l1, l2)
