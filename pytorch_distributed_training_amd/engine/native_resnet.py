@@ -183,6 +183,10 @@ class NativeResNet:
         self._fused_bwd_stats = bool(getattr(ops, "fused_bwd_stats", False)) and self.device.type == "cuda" \
             and os.environ.get("PDT_FUSED_BWD_STATS", "1") == "1"
         self._fused_pool_bwd = os.environ.get("PDT_FUSED_POOL_BWD", "1") == "1"
+        # ... and its backward sums come out of the first block's data-gradient epilogue (no pass over the 112x112
+        # tensor for them): the pooling keeps the winners' values and the pooled tensor's packed sign mask
+        self._pool_winners = self._fused_pool_bwd and self._fused_bwd_stats and bool(getattr(ops, "pool_winners", False)) \
+            and os.environ.get("PDT_POOL_WINNERS", "1") == "1"
         # ReLU backward of a block output from a packed bit mask written by the pass that produced
         # the tensor, instead of re-reading the tensor for its sign in the data-gradient epilogue.
         self._relu_bits = bool(getattr(ops, "relu_bits", False)) and os.environ.get("PDT_RELU_BITS", "1") == "1"
@@ -751,7 +755,12 @@ class NativeResNet:
                 scale, shift = ctx.scale, ctx.shift
             else:
                 scale, shift = self._affine_eval(stem)
-            x, idx = ops.bn_relu_maxpool_fwd(y, scale, shift)
+            if train and self._pool_winners:
+                # keep y at the pooling winners and the pooled tensor's sign mask: the first block's data gradient
+                # then adds up the stem BatchNorm's backward sums itself (see backward)
+                x, idx, self._saved["pool_ywin"] = ops.bn_relu_maxpool_fwd(y, scale, shift, winners=True)
+            else:
+                x, idx = ops.bn_relu_maxpool_fwd(y, scale, shift)
             if train:
                 self._saved["stem_shape"] = tuple(y.shape)
                 self._saved["pool_idx"] = idx
@@ -1015,6 +1024,13 @@ class NativeResNet:
         if prev_last is not None and self._bn_fold_product \
                 and self._can_fold(prev_last, self._ysize(self._ctx[prev_last.bn])):
             skw, pre = {"out_sums": True}, "s0"      # that unit is folded: all it wants with g is sum g
+        elif prev_last is None and bits is not None and "pool_ywin" in self._saved:
+            # The first block: its input gradient belongs to the max-pooled stem activation.  Every pooling window
+            # hands its gradient to one element of the stem BatchNorm's output, so that layer's backward sums are
+            # sums over the windows -- of this gradient (masked here) times the winner's value.
+            c0 = self._ctx[self.spec.stem.bn]
+            skw = {"bwd_stats": (self._saved.pop("pool_ywin"), c0.mean, c0.scale, c0.shift, MASK_NONE)}
+            pre = True
         else:
             # the fused backward sums of the previous block's last BatchNorm need the packed mask
             skw = (self._bstats(prev_last, MASK_NONE) or {}) if (bits is not None or not self._relu_bits_only) else {}
@@ -1046,7 +1062,7 @@ class NativeResNet:
             pool_idx, stem_shape = self._saved.pop("pool_idx"), self._saved.pop("stem_shape")
             if self._fused_pool_bwd:
                 # the dense 112x112 gradient of the pooling is never materialised
-                dy = self._bn_backward(stem, ctx, g, None, MASK_RECOMPUTE, pool_idx=pool_idx)
+                dy = self._bn_backward(stem, ctx, g, None, MASK_RECOMPUTE, prereduced=pre is True, pool_idx=pool_idx)
             else:
                 da = ops.maxpool_bwd(g, pool_idx, stem_shape)
                 dy = self._bn_backward(stem, ctx, da, None, MASK_RECOMPUTE)

@@ -372,11 +372,18 @@ PDT_API int pdt_input_pad(const void* src, void* dst, int B, int H, int W, int H
 // AFFINE: the input is a raw conv output and relu(x*scale + shift), rounded to bf16 exactly as the
 // stand-alone BatchNorm-apply pass would store it, is pooled instead -- the stem's normalised
 // 112x112 activation is never written.
-template <bool AFFINE>
+// WINNERS (with AFFINE): also stores the raw input value of every window's winner and the packed sign mask of the
+// pooled result (bit k of byte i = channel 8i + k), so that the kernel which later produces the gradient of the pooled
+// tensor can apply this ReLU's backward from the mask and add up the BatchNorm-backward sums of the layer in front
+// of the pooling in its epilogue: sum(dy) and sum(dy * (y - mean)) over the dense tensor are sums over the windows of
+// the pooled gradient times the winner's value, because every window hands its gradient to exactly one element.
+template <bool AFFINE, bool WINNERS = false>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ out,
                                                            unsigned char* __restrict__ idx, int B, int H, int W,
                                                            int C, int Ho, int Wo, const float* __restrict__ scale,
-                                                           const float* __restrict__ shift) {
+                                                           const float* __restrict__ shift,
+                                                           bf16* __restrict__ ywin = nullptr,
+                                                           unsigned char* __restrict__ bits = nullptr) {
     int cvec = C / 8;
     long long total = (long long)B * Ho * Wo * cvec;
     long long stride = (long long)gridDim.x * blockDim.x;
@@ -389,28 +396,39 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16* __restrict
         int wo = (int)(t - t2 * (unsigned)Wo);
         int b = (int)(t2 / (unsigned)Ho);
         int ho = (int)(t2 - (unsigned)b * (unsigned)Ho);
-        float best[8], sc[8], sh[8];
-        unsigned char bi[8];
+        float best[8], sc[8], sh[8], raw[WINNERS ? 8 : 1];
+        unsigned bi[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             best[k] = -INFINITY;
             bi[k] = 0;
+            if (WINNERS) raw[k] = 0.0f;
             if (AFFINE) { sc[k] = scale[cv * 8 + k]; sh[k] = shift[cv * 8 + k]; }
         }
+        // all nine window positions are loaded unconditionally and back to back (a position outside the image re-reads
+        // the window's centre, which always exists, and is given -inf): with a branch per position a wave has one load
+        // in flight at a time
+        bf16x8 v[9];
+        bool ok[9];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            int h = ho * 2 - 1 + r;
-            if (h < 0 || h >= H) continue;
+        for (int q = 0; q < 9; ++q) {
+            const int h = ho * 2 - 1 + q / 3, w = wo * 2 - 1 + q % 3;
+            ok[q] = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+            const int hc = ok[q] ? h : ho * 2, wc = ok[q] ? w : wo * 2;
+            v[q] = ld_bf16x8(x + (((long long)b * H + hc) * W + wc) * C + cv * 8);
+        }
 #pragma unroll
-            for (int s2 = 0; s2 < 3; ++s2) {
-                int w = wo * 2 - 1 + s2;
-                if (w < 0 || w >= W) continue;
-                bf16x8 v = ld_bf16x8(x + (((long long)b * H + h) * W + w) * C + cv * 8);
+        for (int q = 0; q < 9; ++q) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    float f = bf2f(v[k]);
-                    if (AFFINE) f = bf2f(f2bf(fmaxf(f * sc[k] + sh[k], 0.0f)));
-                    if (f > best[k]) { best[k] = f; bi[k] = (unsigned char)(r * 3 + s2); }
+            for (int k = 0; k < 8; ++k) {
+                const float f0 = bf2f(v[q][k]);
+                float f = f0;
+                if (AFFINE) f = bf2f(f2bf(fmaxf(f * sc[k] + sh[k], 0.0f)));
+                f = ok[q] ? f : -INFINITY;
+                if (f > best[k]) {
+                    best[k] = f;
+                    bi[k] = (unsigned)q;
+                    if (WINNERS) raw[k] = f0;
                 }
             }
         }
@@ -420,6 +438,17 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16* __restrict
         for (int k = 0; k < 8; ++k) { o[k] = f2bf(best[k]); packed |= (unsigned long long)bi[k] << (8 * k); }
         st_bf16x8(out + i * 8, o);
         reinterpret_cast<unsigned long long*>(idx)[i] = packed;
+        if (WINNERS) {
+            bf16x8 r;
+            unsigned m8 = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                r[k] = f2bf(raw[k]);
+                m8 |= (best[k] > 0.0f ? 1u : 0u) << k;
+            }
+            st_bf16x8(ywin + i * 8, r);
+            bits[i] = (unsigned char)m8;
+        }
     }
 }
 
@@ -539,6 +568,19 @@ PDT_API int pdt_bn_relu_maxpool_fwd(const void* y, const float* scale, const flo
     if (total >= 0x7fffffffLL) return -3;
     hipLaunchKernelGGL(maxpool_fwd_kernel<true>, dim3(ew_grid(total, 1)), dim3(256), 0, s, (const bf16*)y, (bf16*)out,
                        (unsigned char*)idx, B, H, W, C, Ho, Wo, scale, shift);
+    return pdt_launch_status();
+}
+
+// ... and the winners' raw values plus the packed sign mask of the result (see maxpool_fwd_kernel)
+PDT_API int pdt_bn_relu_maxpool_fwd_winners(const void* y, const float* scale, const float* shift, void* out, void* idx,
+                                            void* ywin, void* bits, int B, int H, int W, int C, int Ho, int Wo,
+                                            hipStream_t s) {
+    if (C % 8 || !ywin || !bits) return -1;
+    long long total = (long long)B * Ho * Wo * (C / 8);
+    if (total >= 0x7fffffffLL) return -3;
+    hipLaunchKernelGGL((maxpool_fwd_kernel<true, true>), dim3(ew_grid(total, 1)), dim3(256), 0, s, (const bf16*)y,
+                       (bf16*)out, (unsigned char*)idx, B, H, W, C, Ho, Wo, scale, shift, (bf16*)ywin,
+                       (unsigned char*)bits);
     return pdt_launch_status();
 }
 

@@ -48,6 +48,7 @@ _sig("pdt_crop_resize_flip", _vp, _vp, _vp, _i, _i, _i, _vp)
 _sig("pdt_maxpool_fwd", _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
 _sig("pdt_bn_relu_maxpool_fwd", _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
 _sig("pdt_maxpool_bwd", _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
+_sig("pdt_bn_relu_maxpool_fwd_winners", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
 _sig("pdt_pool_bn_bwd_reduce_accum", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp)
 _sig("pdt_pool_bn_bwd_elemt", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _vp)
 _sig("pdt_avgpool_fwd", _vp, _vp, _i, _i, _i, _vp)
@@ -852,8 +853,8 @@ def bn_bwd_reduce(g, y, mean, invstd, scale, shift, mask_src, mask_mode: int, dg
     C = y.shape[-1]
     rows = y.numel() // C
     acc = _accumulator(y.device, C, "bwd")
-    if pool_idx is not None:
-        if mask_mode != MASK_RECOMPUTE or prereduced:
+    if pool_idx is not None and not prereduced:
+        if mask_mode != MASK_RECOMPUTE:
             raise ValueError("bn_bwd_reduce: pool_idx goes with the recomputed ReLU mask")
         B, H, W, _, Ho, Wo = _pool_geometry(g, y, "bn_bwd_reduce")
         rc = _lib.pdt_pool_bn_bwd_reduce_accum(_p(g), _p(pool_idx), _p(y), _p(mean), _p(scale), _p(shift), _p(acc),
@@ -1136,13 +1137,27 @@ def maxpool_fwd(x):
     return out, idx
 
 
-def bn_relu_maxpool_fwd(y, scale, shift):
-    """``maxpool3x3s2(relu(y*scale + shift))`` without materialising the normalised tensor."""
+pool_winners = True          # bn_relu_maxpool_fwd(winners=True)
+
+
+def bn_relu_maxpool_fwd(y, scale, shift, winners: bool = False):
+    """``maxpool3x3s2(relu(y*scale + shift))`` without materialising the normalised tensor.  ``winners``: also
+    returns ``y`` at every window's winner (``[B, Ho, Wo, C]``) and attaches the packed sign mask of the pooled
+    result to it -- what the kernel producing the pooled gradient needs to apply this ReLU's backward and to add up
+    the BatchNorm-backward sums of ``y``'s layer on the way (``conv_dgrad(relu_bits=, bwd_stats=)``)."""
     y = _bf16c(y, "bn_relu_maxpool_fwd")
     B, H, W, C = y.shape
     Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
     out = torch.empty(B, Ho, Wo, C, dtype=torch.bfloat16, device=y.device)
     idx = torch.empty(B, Ho, Wo, C, dtype=torch.uint8, device=y.device)
+    if winners:
+        ywin = torch.empty_like(out)
+        bits = new_relu_bits(out)
+        rc = _lib.pdt_bn_relu_maxpool_fwd_winners(_p(y), _p(scale), _p(shift), _p(out), _p(idx), _p(ywin), _p(bits),
+                                                  B, H, W, C, Ho, Wo, _stream())
+        _check(rc, "pdt_bn_relu_maxpool_fwd_winners")
+        out._pdt_relu_bits = bits
+        return out, idx, ywin
     rc = _lib.pdt_bn_relu_maxpool_fwd(_p(y), _p(scale), _p(shift), _p(out), _p(idx), B, H, W, C, Ho, Wo, _stream())
     _check(rc, "pdt_bn_relu_maxpool_fwd")
     return out, idx

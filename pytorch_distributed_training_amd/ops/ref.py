@@ -461,9 +461,21 @@ def maxpool_fwd(x: torch.Tensor):
     return _nhwc(out).to(x.dtype), idx
 
 
-def bn_relu_maxpool_fwd(y, scale, shift):
-    """``maxpool3x3s2(relu(y*scale + shift))``: the stem's BatchNorm-apply and pooling in one op."""
-    return maxpool_fwd(bn_apply(y, scale, shift, None, True))
+pool_winners = True
+
+
+def bn_relu_maxpool_fwd(y, scale, shift, winners: bool = False):
+    """``maxpool3x3s2(relu(y*scale + shift))``: the stem's BatchNorm-apply and pooling in one op.  ``winners``: also
+    ``y`` at every window's winner, and the packed sign mask of the pooled result attached to it."""
+    out, idx = maxpool_fwd(bn_apply(y, scale, shift, None, True))
+    if not winners:
+        return out, idx
+    B, H, W, C = y.shape
+    ywin = _nhwc(_nchw(y.float()).reshape(B, C, -1).gather(2, idx.reshape(B, C, -1)).view(idx.shape)).to(y.dtype)
+    bits = new_relu_bits(out)
+    _pack_bits(out, bits)
+    out._pdt_relu_bits = bits
+    return out, idx, ywin
 
 
 def maxpool_bwd(dout: torch.Tensor, idx: torch.Tensor, in_shape) -> torch.Tensor:

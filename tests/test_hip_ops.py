@@ -303,7 +303,7 @@ def test_batched_weight_transpose(hip, device):
         assert torch.equal(wt[o:o + n], ref_t)
 
 
-@pytest.mark.parametrize("B,H,C", [(2, 112, 64), (3, 30, 64), (1, 8, 128)])
+@pytest.mark.parametrize("B,H,C", [(2, 112, 64), (3, 30, 64), (1, 8, 128), (3, 32, 128), (2, 16, 64)])
 def test_pooling(hip, device, B, H, C):
     torch.manual_seed(B + H)
     x = torch.relu(rnd(B, H, H, C, device=device))       # many exact ties at 0, like post-ReLU activations
@@ -404,7 +404,7 @@ def test_half_resolution_addend(hip, device, k, stride, pad, fused):
     assert rel_err(b, c) < 1.5e-2
 
 
-@pytest.mark.parametrize("B,H,C", [(2, 112, 64), (3, 30, 64), (1, 9, 128)])
+@pytest.mark.parametrize("B,H,C", [(2, 112, 64), (3, 30, 64), (1, 9, 128), (3, 32, 128), (2, 16, 256)])
 def test_bn_backward_through_fused_relu_maxpool(hip, device, B, H, C):
     """BatchNorm-backward passes fed with the POOLED gradient + winner indices against the
     materialised pooling gradient followed by the ordinary passes."""
@@ -436,6 +436,44 @@ def test_bn_backward_through_fused_relu_maxpool(hip, device, B, H, C):
                             pool_idx=idx_r)
     assert torch.allclose(sums1, sums_r, **tol)
     assert rel_err(dx1, dx_r) < 2e-2
+
+
+@pytest.mark.parametrize("B,H,C", [(4, 112, 64), (3, 30, 64), (2, 18, 128)])
+def test_stem_backward_sums_from_the_first_block_data_gradient(hip, device, B, H, C):
+    """The pooling keeps y at its winners and the pooled tensor's sign mask; a data gradient produced with that mask
+    and ``bwd_stats`` on the winners leaves the same BatchNorm-backward sums as the pass over the dense tensor."""
+    torch.manual_seed(B + H + C)
+    y = rnd(B, H, H, C, device=device)
+    gamma = torch.rand(C, device=device) + 0.5
+    beta = torch.randn(C, device=device) * 0.2
+    mean = y.float().mean(dim=(0, 1, 2))
+    invstd = (y.float().var(dim=(0, 1, 2), unbiased=False) + 1e-5).rsqrt()
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    pooled, idx, ywin = hip.bn_relu_maxpool_fwd(y, scale, shift, winners=True)
+    p0, i0 = hip.bn_relu_maxpool_fwd(y, scale, shift)
+    assert torch.equal(pooled, p0) and torch.equal(idx, i0)
+    pr, ir, ywin_r = ref.bn_relu_maxpool_fwd(y, scale, shift, winners=True)
+    assert torch.equal(pooled, pr) and torch.equal(ywin, ywin_r)
+    assert torch.equal(pooled._pdt_relu_bits, pr._pdt_relu_bits)
+    # a 1x1 convolution's data gradient lands on the pooled tensor (as the first bottleneck block's does)
+    Co = 64
+    w = rnd(Co, 1, 1, C, device=device, scale=0.1)
+    wt = torch.empty(C, 1, 1, Co, dtype=torch.bfloat16, device=device)
+    hip.transpose_weights(w, wt)
+    dy = rnd(B, pooled.shape[1], pooled.shape[2], Co, device=device)
+    addend = rnd(*pooled.shape, device=device)
+    bits = pooled._pdt_relu_bits
+    g_plain = hip.conv_dgrad(dy, w, wt, tuple(pooled.shape), 1, 1, 1, 0, addend=addend, relu_bits=bits)
+    g = hip.conv_dgrad(dy, w, wt, tuple(pooled.shape), 1, 1, 1, 0, addend=addend, relu_bits=bits,
+                       bwd_stats=(ywin, mean, scale, shift, ref.MASK_NONE))
+    assert torch.equal(g, g_plain)
+    dg1, db1 = torch.zeros(C, device=device), torch.zeros(C, device=device)
+    sums1 = hip.bn_bwd_reduce(g, y, mean, invstd, scale, shift, None, ref.MASK_RECOMPUTE, dg1, db1, prereduced=True,
+                              pool_idx=idx)
+    dg0, db0 = torch.zeros(C, device=device), torch.zeros(C, device=device)
+    sums0 = hip.bn_bwd_reduce(g, y, mean, invstd, scale, shift, None, ref.MASK_RECOMPUTE, dg0, db0, pool_idx=idx)
+    tol = dict(rtol=2e-3, atol=2e-3 * sums0.abs().max().item())
+    assert torch.allclose(sums1, sums0, **tol) and torch.allclose(dg1, dg0, **tol) and torch.allclose(db1, db0, **tol)
 
 
 @pytest.mark.parametrize("B,K,N", [(64, 2048, 1000), (7, 512, 10)])
