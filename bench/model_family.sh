@@ -2,7 +2,7 @@
 # Throughput of every model family on one MI355X:  bench/model_family.sh [OUT_FILE] [BATCH]
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 OUT="${1:-$ROOT/gpurun_out/model_family.txt}"
-BATCH="${2:-512}"
+BATCH="${2:-1024}"
 cd "$ROOT"
 : > "$OUT"
 for m in ResNet18 ResNet34 ResNet50 ResNet101 ResNet152; do

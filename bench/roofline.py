@@ -1,7 +1,7 @@
 """Per-dispatch roofline of the training step: minimum bytes and FLOPs of every library call of one
 recorded step, joined with a rocprofv3 kernel trace of the same step.
 
-    python bench/roofline.py dump OPLIST.json [--batch 512] [--model ResNet50]     (on the GPU)
+    python bench/roofline.py dump OPLIST.json [--batch 1024] [--model ResNet50]     (on the GPU)
     rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 bench.py ...     (same batch / model)
     python bench/roofline.py join OPLIST.json TRACE.csv [--steps 4] [--top 40]
 
@@ -103,6 +103,10 @@ def _entry(name, a):
     if name == "pdt_bn_relu_maxpool_fwd":
         B, H, W, C, Ho, Wo = a[5:11]
         return dict(kind="maxpool_fwd", bytes=B * H * W * C * 2 + B * Ho * Wo * C * 3, flops=0, desc=f"B{B} {H}x{W}x{C}")
+    if name == "pdt_bn_relu_maxpool_fwd_winners":
+        B, H, W, C, Ho, Wo = a[7:13]
+        return dict(kind="maxpool_fwd", bytes=B * H * W * C * 2 + B * Ho * Wo * (C * 5 + C // 8), flops=0,
+                    desc=f"B{B} {H}x{W}x{C} +winners")
     if name in ("pdt_pool_bn_bwd_reduce_accum", "pdt_pool_bn_bwd_elemt"):
         off = 7 if name.endswith("accum") else 10
         B, H, W, C, Ho, Wo = a[off:off + 6]
@@ -134,6 +138,7 @@ KERNEL_OF = {
     "pdt_bn_moments": "bn_moments_kernel", "pdt_bn_finalize": "bn_finalize_kernel",
     "pdt_bn_finalize_fused": "bn_finalize_fused_kernel", "pdt_bn_bwd_sums": "bn_bwd_sums_kernel",
     "pdt_bn_bwd_sums_fused": "bn_bwd_sums_fused_kernel", "pdt_bn_relu_maxpool_fwd": "maxpool_fwd_kernel",
+    "pdt_bn_relu_maxpool_fwd_winners": "maxpool_fwd_kernel",
     "pdt_pool_bn_bwd_reduce_accum": "pool_bn_bwd_reduce_kernel", "pdt_pool_bn_bwd_elemt": "pool_bn_bwd_elemt_kernel",
     "pdt_input_pad": "input_pad_kernel", "pdt_avgpool_fwd": "avgpool_fwd_kernel", "pdt_avgpool_bwd": "avgpool_bwd_kernel",
     "pdt_softmax_ce": "softmax_ce_kernel", "pdt_colsum_add": "colsum_kernel", "pdt_zero_f32": "zero_f32_kernel",
@@ -261,7 +266,7 @@ def main() -> None:
     sub = ap.add_subparsers(dest="cmd", required=True)
     d = sub.add_parser("dump")
     d.add_argument("oplist")
-    d.add_argument("--batch", type=int, default=512)
+    d.add_argument("--batch", type=int, default=1024)
     d.add_argument("--model", default="ResNet50")
     j = sub.add_parser("join")
     j.add_argument("oplist")
