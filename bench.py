@@ -15,6 +15,7 @@ A step is the full training iteration of the trainer: host-to-device copy of a s
 uint8 ImageNet-shaped batch (prefetched on a copy stream), fused normalise/layout kernel,
 forward, loss, backward with SyncBatchNorm (N > 1) and bucketed gradient all-reduce
 overlapped on a side stream, fused SGD step.  Weak scaling: the per-GPU batch is fixed.
+Three set-up steps in which the engine records its step program (``--setup-steps``, reported in the JSON line),
 W un-timed warm-up steps, then exactly K timed steps bracketed by barrier +
 ``torch.cuda.synchronize()``; the time is the MAX over ranks; rank 0 prints one JSON line.
 """
@@ -135,6 +136,8 @@ def main() -> int:
     ap.add_argument("--bucket-cap-mb", type=float, default=25.0)
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--backend", type=str, default="nccl")
+    ap.add_argument("--setup-steps", type=int, default=3,
+                    help="untimed steps before the warm-up in which the engine records its step (see main)")
     args = ap.parse_args()
 
     hang_dump = float(os.environ.get("PDT_HANG_DUMP_S", "0") or 0)
@@ -180,6 +183,11 @@ def main() -> int:
         return engine.train_step(img, label)
 
     loss = None
+    # Set-up, before the warm-up proper: the engine runs the first step of a batch shape eagerly (it fills its lazily
+    # built caches), records the second as a command list and replays that from the third on -- what a tracing compiler
+    # would do at build time.  Untimed, counted separately from the W warm-up steps and reported as "setup_steps".
+    for _ in range(args.setup_steps):
+        loss = step()
     for _ in range(args.warmup):
         loss = step()
     if not engine.check_health():                 # collective; a failed exchange would have poisoned the warm-up
@@ -225,6 +233,7 @@ def main() -> int:
             "data": f"synthetic ImageNet-shaped ({args.input_format}, {args.data_mode}), random-init weights",
             "config": {
                 "model": args.model, "global_batch": global_batch, "per_gpu_batch": args.batch,
+                "setup_steps": args.setup_steps,
                 "image_size": args.image_size, "seq_len": None,
                 "parallelism": f"dp{info.world_size}" + ("+syncbn" if (args.sync_bn and info.world_size > 1) else ""),
                 "engine": args.engine, "optimizer": "SGD momentum 0.9 wd 1e-4", "final_loss": round(final_loss, 4),
