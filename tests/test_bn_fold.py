@@ -112,6 +112,30 @@ def test_engine_with_and_without_the_folded_path(monkeypatch):
     assert cos > 0.99, cos
 
 
+def test_stem_backward_sums_are_sums_over_the_pooling_windows():
+    """Every 3x3/s2 pooling window hands its gradient to one element, so the BatchNorm-backward sums of the layer
+    under ReLU + max pooling are sums over the windows of (masked pooled gradient) x (the winner's value): what the
+    first block's data-gradient epilogue adds up on the GPU instead of a pass over the dense tensor."""
+    torch.manual_seed(11)
+    B, H, C = 3, 14, 16
+    y = torch.randn(B, H, H, C)
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.2
+    mean = y.mean(dim=(0, 1, 2))
+    invstd = (y.var(dim=(0, 1, 2), unbiased=False) + 1e-5).rsqrt()
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    pooled, idx, ywin = ref.bn_relu_maxpool_fwd(y, scale, shift, winners=True)
+    p0, i0 = ref.bn_relu_maxpool_fwd(y, scale, shift)
+    assert torch.equal(pooled, p0) and torch.equal(idx, i0)
+    # the winner's normalised value is the pooled value wherever the window is not all-zero
+    assert torch.allclose(torch.relu(ywin * scale + shift), pooled, atol=1e-6)
+    g = torch.randn_like(pooled) * ref._unpack_bits(pooled._pdt_relu_bits)        # the ReLU mask is already applied
+    assert torch.equal(ref._unpack_bits(pooled._pdt_relu_bits), (pooled > 0).to(g.dtype))
+    dense = ref.bn_bwd_reduce(g, y, mean, invstd, scale, shift, None, ref.MASK_RECOMPUTE, pool_idx=idx)
+    g2 = g.reshape(-1, C)
+    windows = torch.stack([g2.sum(0), (g2 * (ywin.reshape(-1, C) - mean)).sum(0) * invstd])
+    assert torch.allclose(windows, dense, rtol=1e-4, atol=1e-4)
+
+
 def test_fused_block_tail_reference_ops():
     """Statistics of a 1x1 convolution's output from the Gram matrix of its input, and the block tail as ONE product
     with BatchNorm folded into the weights, against the plain sequence conv -> statistics -> bn_apply(2)."""
