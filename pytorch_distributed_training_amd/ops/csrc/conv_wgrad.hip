@@ -38,6 +38,9 @@ static const int g_pdt_wgrad_dma = env_int("PDT_WGRAD_DMA", 0);
 static const int g_pdt_wgrad_blocks = env_int("PDT_WGRAD_BLOCKS", 1024);   // tuned inside the step, not stand-alone
 static const int g_pdt_wgrad_atomic_mb = env_int("PDT_WGRAD_ATOMIC_MB", 24);
 static const int g_pdt_wgrad_big_tile = env_int("PDT_WGRAD_BIG_TILE", 1);      // tile of the layers with N, Ci > 64
+// layers with 64 channels on ONE side: 1 = a tile that is 128 wide on the other side (the 64-wide operand is read twice
+// per 128 instead of twice per 64 channels of the other one), 0 = 64 x 64
+static const int g_pdt_wgrad_wide_small = env_int("PDT_WGRAD_WIDE_SMALL", 1);
 
 #define MAX_TAPS 52
 #define BKP 64   // pixels per K step
@@ -720,7 +723,7 @@ static int launch_wgrad(WgradParams& p, hipStream_t s, int target_blocks, long l
 
 // tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 64x32 (one tap per workgroup), 4 = 128x64,
 //       5 = 64x32 with all 7 taps per workgroup (the stem; auto picks it for T == 7, Ci <= 32),
-//       6 / 7 = 64x64 / 128x64 with three taps (one kernel row) per workgroup, Ci <= 64
+//       6 / 7 = 64x64 / 128x64 with three taps (one kernel row) per workgroup, Ci <= 64; 9 = 64x128
 // ws / ws_bytes: workspace of the deterministic variant (NULL: float atomics).  It must stay untouched by other
 // streams until this launch has finished: one workspace per stream that issues weight gradients.
 // row_scale: optional [N] factor applied to output row n before it is added to dw
@@ -773,7 +776,11 @@ PDT_API int pdt_conv_wgrad_ex(const void* dy, const void* in, float* dw, long lo
     if (tile == 0) {
         if (Ci <= 32) tile = (T == 7) ? 5 : 3;
         else if (T == 9 && Ci <= 64) tile = (N <= 64) ? 6 : 7;    // 3x3 on 64 channels: one kernel row per workgroup
-        else if (N <= 64 || Ci <= 64) tile = 2;
+        else if (N <= 64 || Ci <= 64) {
+            tile = 2;
+            if (g_pdt_wgrad_wide_small && N <= 64 && Ci >= 128) tile = 9;
+            if (g_pdt_wgrad_wide_small && Ci <= 64 && N >= 128) tile = 4;
+        }
         else {
             tile = g_pdt_wgrad_big_tile;
             p.use_dma = tile == 1 && dma_ok && g_pdt_wgrad_dma;
@@ -787,6 +794,7 @@ PDT_API int pdt_conv_wgrad_ex(const void* dy, const void* in, float* dw, long lo
         case 5: return launch_wgrad_taps<64, 32, 2, 2, 7>(p, s, user_blocks ? target_blocks : 768, ws_slabs);
         case 6: return launch_wgrad_taps<64, 64, 2, 2, 3>(p, s, target_blocks, ws_slabs);
         case 7: return launch_wgrad_taps<128, 64, 2, 2, 3>(p, s, target_blocks, ws_slabs);
+        case 9: return launch_wgrad<64, 128, 2, 2>(p, s, target_blocks, budget, ws_slabs);
         default: return -6;
     }
 }

@@ -150,6 +150,10 @@ WGRAD = [
     # tile 8: the LDS-DMA 128 x 128 kernel forced (linear 1x1, 3x3 with padding taps, stride 2, channel remainders)
     (64, 14, 1024, 256, 1, 1, 0, 8), (64, 14, 256, 256, 3, 1, 1, 8), (16, 56, 128, 128, 3, 2, 1, 8),
     (64, 28, 256, 512, 1, 2, 0, 8), (16, 28, 192, 320, 1, 1, 0, 8), (8, 14, 136, 200, 3, 1, 1, 8),
+    # 64 channels on one side: the automatic choice is 128 wide on the other (64 x 128 / 128 x 64); tile 9 forced on
+    # a 3x3 layer and with channel remainders
+    (16, 56, 256, 64, 1, 1, 0, 0), (16, 56, 64, 256, 1, 1, 0, 0), (16, 28, 128, 64, 3, 1, 1, 9),
+    (16, 28, 200, 72, 1, 1, 0, 9),
 ]
 
 

@@ -127,7 +127,7 @@ def test_conv_launches_split_over_the_batch(hip, device, monkeypatch, k, stride,
     assert rel_err(split[4], whole[4]) < 1e-4
 
 
-@pytest.mark.parametrize("tile", [1, 2, 4, 8])
+@pytest.mark.parametrize("tile", [1, 2, 4, 8, 9])
 def test_wgrad_tiles(hip, device, tile):
     torch.manual_seed(tile)
     x = rnd(3, 14, 14, 128, device=device)
