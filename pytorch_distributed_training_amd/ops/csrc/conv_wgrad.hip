@@ -28,14 +28,15 @@
 // Measurement switches (read once): PDT_WGRAD_DMA=1 lets the automatic choice use the LDS-DMA 128 x 128 kernel
 // (off by default: inside the training step it measured 0.9 ms slower than the register-staged kernel, because the
 // weight gradients run in the shadow of the critical stream and the DMA version takes more bandwidth from it);
-// PDT_WGRAD_BLOCKS / PDT_WGRAD_ATOMIC_MB override the split-K sizing defaults (1024 workgroups / 24 MB: the step is
-// fastest there -- 512 and 2048 workgroups are both 0.45 ms slower, 12 MB is 1.3 ms slower, 48 MB 0.2 ms).
+// PDT_WGRAD_BLOCKS / PDT_WGRAD_ATOMIC_MB override the split-K sizing defaults (768 workgroups = three per CU / 24 MB:
+// the step is fastest there at per-GPU batch 512 and 1024 -- 1024 workgroups are 0.15-0.2 ms slower, 512 and 640
+// 0.5-0.7 ms, 2048 0.6 ms; 12 MB is 1.3 ms slower, 48 MB 0.2 ms).
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return (e && *e) ? atoi(e) : dflt;
 }
 static const int g_pdt_wgrad_dma = env_int("PDT_WGRAD_DMA", 0);
-static const int g_pdt_wgrad_blocks = env_int("PDT_WGRAD_BLOCKS", 1024);   // tuned inside the step, not stand-alone
+static const int g_pdt_wgrad_blocks = env_int("PDT_WGRAD_BLOCKS", 768);    // tuned inside the step, not stand-alone (three per CU)
 static const int g_pdt_wgrad_atomic_mb = env_int("PDT_WGRAD_ATOMIC_MB", 24);
 static const int g_pdt_wgrad_big_tile = env_int("PDT_WGRAD_BIG_TILE", 1);      // tile of the layers with N, Ci > 64
 // layers with 64 channels on ONE side: 1 = a tile that is 128 wide on the other side (the 64-wide operand is read twice
