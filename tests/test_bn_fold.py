@@ -324,6 +324,41 @@ def test_hip_dgrad_leaves_the_sums_of_its_result(hip, device):
 
 
 @pytest.mark.gpu
+def test_hip_engine_with_the_width_limit_of_the_fold(hip, device, monkeypatch):
+    """The shipped rule folds units of at most 1024 output channels: stages 1-3 of ResNet-50 run folded / fused,
+    stage 4 runs the plain passes, in one step -- against the step with every unit folded and with none."""
+    from pytorch_distributed_training_amd.engine.native_resnet import NativeResNet
+    from pytorch_distributed_training_amd.models import get_model, get_spec
+
+    torch.manual_seed(6)
+    state = get_model("ResNet50", 10).state_dict()
+    img = torch.randn(8, 3, 64, 64, device=device)
+    label = torch.randint(0, 10, (8,), device=device)
+    monkeypatch.setenv("PDT_BN_FOLD_MIN_MB", "0")
+    monkeypatch.setenv("PDT_FWD_FUSE", "0")              # same forward pass in all three, so gradients compare tightly
+    grads, losses = [], []
+    for on, limit in (("1", "1024"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("PDT_BN_FOLD", on)
+        monkeypatch.setenv("PDT_BN_FOLD_MAX_COUT", limit)
+        eng = NativeResNet(get_spec("ResNet50", 10), device, hip, torch.bfloat16, hip_graphs=True)
+        eng.load_state_dict(state)
+        last4 = eng.spec.blocks[-1].units[-1]
+        assert eng._can_fold(last4, 1 << 30) == (on == "1" and limit == "0")
+        assert eng._can_fold(eng.spec.blocks[0].units[-1], 1 << 30) == (on == "1")
+        for _ in range(3):                               # eager, recorded, replayed
+            loss = float(eng.forward_backward(img, label))
+            torch.cuda.synchronize()
+            last = eng.params.g.clone()
+            eng.params.g.zero_()
+        losses.append(loss)
+        grads.append(last)
+    assert abs(losses[0] - losses[2]) < 1e-3 and abs(losses[1] - losses[2]) < 1e-3
+    for key, e in eng.params.entries.items():
+        a, b = grads[0][e.offset:e.offset + e.numel], grads[2][e.offset:e.offset + e.numel]
+        assert torch.nn.functional.cosine_similarity(a, b, dim=0).item() > 0.99, key
+
+
+@pytest.mark.gpu
 def test_hip_engine_with_and_without_the_folded_path(hip, device, monkeypatch):
     from pytorch_distributed_training_amd.engine.native_resnet import NativeResNet
     from pytorch_distributed_training_amd.models import get_model, get_spec
