@@ -546,7 +546,7 @@ static int g1_launch(const ConvDmaParams& p, hipStream_t s) {
 }
 
 // tile: 0 = auto (3 when N is a multiple of 128, else 4); 3 = 128 x 128 with K slices of 64 and two stages, 4 = 128 x 64
-// with K slices of 64 and three stages (1 / 2 are old names of 3 / 4); 5 = 128 x 64 with K slices of 32 and four stages,
+// with K slices of 64 and two stages (1 / 2 are old names of 3 / 4); 5 = 128 x 64 with K slices of 32 and four stages,
 // for operands with 32 channels per tap (the stem), never chosen automatically
 // Persistent grid size (resident workgroups) of a kernel variant: tile 3 / 4, with or without the backward-sums epilogue
 // and the second-operand path (diagnostics).
@@ -555,8 +555,8 @@ PDT_API int pdt_conv_dma_resident(int tile, int bstat, int fold) {
         if (fold) return bstat ? g1_resident_blocks<128, 2, 2, 64, 2, true, true>() : g1_resident_blocks<128, 2, 2, 64, 2, false, true>();
         return bstat ? g1_resident_blocks<128, 2, 2, 64, 2, true>() : g1_resident_blocks<128, 2, 2, 64, 2, false>();
     }
-    if (fold) return bstat ? g1_resident_blocks<64, 4, 1, 64, 3, true, true>() : g1_resident_blocks<64, 4, 1, 64, 3, false, true>();
-    return bstat ? g1_resident_blocks<64, 4, 1, 64, 3, true>() : g1_resident_blocks<64, 4, 1, 64, 3, false>();
+    if (fold) return bstat ? g1_resident_blocks<64, 4, 1, 64, 2, true, true>() : g1_resident_blocks<64, 4, 1, 64, 2, false, true>();
+    return bstat ? g1_resident_blocks<64, 4, 1, 64, 2, true>() : g1_resident_blocks<64, 4, 1, 64, 2, false>();
 }
 
 // in2 / Ci2 / pix_stride2 / bias: the optional second operand and accumulator start values (see the file header);
@@ -619,7 +619,8 @@ PDT_API int pdt_conv_dma_ex(const void* in, const void* wgt, void* out, const vo
         p.taps[i] = ((int)offy[i] & 0xff) | (((int)offx[i] & 0xff) << 8) | ((int)widx[i] << 16);
     for (int i = T; i < DMA_MAX_TAPS; ++i) p.taps[i] = 0;
     const bool bs = bstat_y != nullptr;
-    // Tiles: 3 = 128 x 128 (2 x 2 waves, K slices of 64, ring of 2), 4 = 128 x 64 (4 x 1 waves, ring of 3).  Tiles 1 / 2
+    // Tiles: 3 = 128 x 128 (2 x 2 waves, K slices of 64, ring of 2), 4 = 128 x 64 (4 x 1 waves, ring of 2: 50 KB of LDS, so the plain
+    // variant -- 164 VGPRs -- runs three workgroups per CU; a ring of 3 measured 5-8 % slower on the 64-channel 3x3 layers).  Tiles 1 / 2
     // named ring-of-4 pipelines on K slices of 32, which measured slower everywhere; they now select 3 / 4.
     if (tile == 1 || tile == 2) tile += 2;
     if (tile == 0) tile = (N % 128 == 0) ? 3 : 4;
@@ -627,11 +628,11 @@ PDT_API int pdt_conv_dma_ex(const void* in, const void* wgt, void* out, const vo
     if (in2 || bias) {
         if (tile == 5) return -11;
         if (tile == 3) return bs ? g1_launch<128, 2, 2, 64, 2, true, true>(p, s) : g1_launch<128, 2, 2, 64, 2, false, true>(p, s);
-        return bs ? g1_launch<64, 4, 1, 64, 3, true, true>(p, s) : g1_launch<64, 4, 1, 64, 3, false, true>(p, s);
+        return bs ? g1_launch<64, 4, 1, 64, 2, true, true>(p, s) : g1_launch<64, 4, 1, 64, 2, false, true>(p, s);
     }
     switch (tile) {
         case 3: return bs ? g1_launch<128, 2, 2, 64, 2, true>(p, s) : g1_launch<128, 2, 2, 64, 2, false>(p, s);
-        case 4: return bs ? g1_launch<64, 4, 1, 64, 3, true>(p, s) : g1_launch<64, 4, 1, 64, 3, false>(p, s);
+        case 4: return bs ? g1_launch<64, 4, 1, 64, 2, true>(p, s) : g1_launch<64, 4, 1, 64, 2, false>(p, s);
         case 5: return g1_launch<64, 4, 1, 32, 4, false>(p, s);       // 128 x 64, K slices of 32, ring of 4: the stem
         default: return -6;
     }

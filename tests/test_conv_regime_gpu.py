@@ -52,7 +52,7 @@ MULTI_TILE = [
     (16, 56, 64, 256, 1, 1, 0, -1), (16, 56, 64, 384, 1, 1, 0, -1), (64, 28, 128, 512, 1, 1, 0, -1),
     (16, 56, 256, 64, 1, 1, 0, -2), (64, 14, 1024, 256, 1, 1, 0, -1), (64, 14, 1024, 256, 1, 1, 0, -2),
     (16, 56, 256, 512, 1, 2, 0, -1), (33, 14, 512, 192, 1, 1, 0, -2), (5, 7, 2048, 512, 1, 1, 0, -1),
-    # the same kernel with K slices of 64: two-stage (128x128) and three-stage (128x64) rings
+    # the same kernel with K slices of 64: 128x128 and 128x64 tiles (two-stage rings)
     (16, 56, 64, 256, 1, 1, 0, -3), (64, 28, 128, 512, 1, 1, 0, -3), (16, 56, 256, 64, 1, 1, 0, -4),
     (64, 14, 1024, 256, 1, 1, 0, -3), (33, 14, 512, 192, 1, 1, 0, -4), (3, 7, 64, 64, 1, 1, 0, -2),
     # ... and with tap tables: 3x3 with zero padding (taps outside the image must read zeros through the DMA), stride 2
