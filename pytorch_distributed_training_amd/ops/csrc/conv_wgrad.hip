@@ -28,16 +28,16 @@
 // Measurement switches (read once): PDT_WGRAD_DMA=1 lets the automatic choice use the LDS-DMA 128 x 128 kernel
 // (off by default: inside the training step it measured 0.9 ms slower than the register-staged kernel, because the
 // weight gradients run in the shadow of the critical stream and the DMA version takes more bandwidth from it);
-// PDT_WGRAD_BLOCKS / PDT_WGRAD_ATOMIC_MB override the split-K sizing defaults (768 workgroups = three per CU / 24 MB:
-// the step is fastest there at per-GPU batch 512 and 1024 -- 1024 workgroups are 0.15-0.2 ms slower, 512 and 640
-// 0.5-0.7 ms, 2048 0.6 ms; 12 MB is 1.3 ms slower, 48 MB 0.2 ms).
+// PDT_WGRAD_BLOCKS / PDT_WGRAD_ATOMIC_MB override the split-K sizing defaults (768 workgroups = three per CU / 24-32
+// MB by batch: the step is fastest there at per-GPU batch 512 and 1024 -- 1024 workgroups are 0.15-0.2 ms slower,
+// 512 and 640 0.5-0.7 ms, 2048 0.6 ms; the budget's measurements are next to its rule in pdt_conv_wgrad_ex).
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return (e && *e) ? atoi(e) : dflt;
 }
 static const int g_pdt_wgrad_dma = env_int("PDT_WGRAD_DMA", 0);
 static const int g_pdt_wgrad_blocks = env_int("PDT_WGRAD_BLOCKS", 768);    // tuned inside the step, not stand-alone (three per CU)
-static const int g_pdt_wgrad_atomic_mb = env_int("PDT_WGRAD_ATOMIC_MB", 24);
+static const int g_pdt_wgrad_atomic_mb = env_int("PDT_WGRAD_ATOMIC_MB", 0);     // 0: by batch (see pdt_conv_wgrad_ex)
 static const int g_pdt_wgrad_big_tile = env_int("PDT_WGRAD_BIG_TILE", 1);      // tile of the layers with N, Ci > 64
 // layers with 64 channels on ONE side: 1 = a tile that is 128 wide on the other side (the 64-wide operand is read twice
 // per 128 instead of twice per 64 channels of the other one), 0 = 64 x 64
@@ -773,7 +773,13 @@ PDT_API int pdt_conv_wgrad_ex(const void* dy, const void* in, float* dw, long lo
     }
     const bool user_blocks = target_blocks > 0;
     if (!user_blocks) target_blocks = g_pdt_wgrad_blocks;
-    long long budget = (long long)(atomic_budget_mb > 0 ? atomic_budget_mb : g_pdt_wgrad_atomic_mb) << 20;
+    // Atomic-traffic budget of the split: 24 MB up to 512 images per launch, 32 MB from 1024 on (the operands grow with
+    // the batch, the output does not; measured inside the step: 18 / 24 / 32 MB give 17.27 / 17.12 / 17.30 ms at batch
+    // 256, 24 / 32 / 48 MB 31.35 / 31.46 / 31.61 at 512 and 59.67 / 59.35 / 59.73 at 1024).
+    const long long images = M / ((long long)Hg * Wg);
+    const int auto_mb = images >= 1024 ? 32 : 24;
+    long long budget = (long long)(atomic_budget_mb > 0 ? atomic_budget_mb
+                                   : (g_pdt_wgrad_atomic_mb > 0 ? g_pdt_wgrad_atomic_mb : auto_mb)) << 20;
     if (tile == 0) {
         if (Ci <= 32) tile = (T == 7) ? 5 : 3;
         else if (T == 9 && Ci <= 64) tile = (N <= 64) ? 6 : 7;    // 3x3 on 64 channels: one kernel row per workgroup
