@@ -405,23 +405,34 @@ PDT_API int pdt_pool_bn_bwd_reduce_accum(const void* dout, const void* idx, cons
 }
 
 // replicas -> sums [sum(dy), sum(dy*xhat)] ; dbeta += sums[0], dgamma += sums[1] ; zero replicas
+// Sixteen lanes per channel, one replica row each per trip, folded by shuffles: a dozen registers per thread, so a
+// wave of this kernel finds room on a SIMD whose register file the co-running weight-gradient waves have almost
+// filled (one thread per channel holding all replicas needed 108 and queued behind them for ~0.1 ms in stage 1).
 __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(float* __restrict__ acc, const float* __restrict__ invstd,
                                                            float* __restrict__ sums, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int C, int nrep) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    // everything this thread reads is requested before anything is written: one round trip
-    const float is = invstd[c];
-    const float db = dbeta ? dbeta[c] : 0.0f, dg = dgamma ? dgamma[c] : 0.0f;
-    float* ptr[2] = {acc + c, acc + C + c};
-    const bool ok[2] = {true, true};
-    float t[2];
-    acc_take_n<2>(ptr, ok, (size_t)2 * C, nrep, t);
-    const float s0 = t[0], s1 = t[1] * is;
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, rl = threadIdx.x & 15;
+    const bool live = c < C;                    // (whole 16-lane groups: the shuffles below stay inside a group)
+    float a0 = 0.0f, a1 = 0.0f;
+    if (live)
+        for (int r = rl; r < nrep; r += 16) {
+            float* q = acc + (size_t)r * 2 * C + c;
+            a0 += q[0];
+            a1 += q[C];
+            q[0] = 0.0f;
+            q[C] = 0.0f;
+        }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        a0 += __shfl_xor(a0, off, 64);
+        a1 += __shfl_xor(a1, off, 64);
+    }
+    if (!live || rl != 0) return;
+    const float s0 = a0, s1 = a1 * invstd[c];
     sums[c] = s0;
     sums[C + c] = s1;
-    if (dbeta) dbeta[c] = db + s0;
-    if (dgamma) dgamma[c] = dg + s1;
+    if (dbeta) dbeta[c] += s0;
+    if (dgamma) dgamma[c] += s1;
 }
 
 // fused: replicas -> local sums (+ local dgamma / dbeta) -> exchange over the ranks -> sums
@@ -461,7 +472,7 @@ PDT_API int pdt_bn_bwd_sums_fused(void* car, float* acc, const float* invstd, fl
 
 PDT_API int pdt_bn_bwd_sums(float* acc, const float* invstd, float* sums, float* dgamma, float* dbeta, int C,
                             hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, acc, invstd, sums, dgamma, dbeta, C,
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(C * 16, 256)), dim3(256), 0, s, acc, invstd, sums, dgamma, dbeta, C,
                        pdt_nrep());
     return pdt_launch_status();
 }
