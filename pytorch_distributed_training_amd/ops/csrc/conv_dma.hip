@@ -21,12 +21,11 @@
 //     K steps per tile (K = 64, 128) the loads of tile t+1 fly under the epilogue of tile t; waits are
 //     counted (s_waitcnt vmcnt(N)) and the barrier is a bare s_barrier, so younger DMA groups and
 //     epilogue stores stay in flight across it;
-//   * the epilogue never touches LDS and needs no barrier: a wave converts its accumulators to bf16
-//     and transposes them between lanes and registers with v_permlane32_swap / v_permlane16_swap
-//     (the MFMA leaves a lane with 4 channels of 4 different 16-channel groups; afterwards it holds
-//     16 CONSECUTIVE channels of one pixel = 32 contiguous bytes), so every epilogue operand
-//     (residual-gradient addend, packed ReLU mask, the BatchNorm input whose backward sums are
-//     being fused) is read and the result written with 16-byte accesses straight from registers;
+//   * the epilogue never touches LDS and needs no barrier: the weight rows are assigned to the MFMA operand rows so
+//     that a lane ends up with 16 CONSECUTIVE channels of one pixel = 32 contiguous bytes (see g1_swz_w), so every
+//     epilogue operand (residual-gradient addend, packed ReLU mask, the BatchNorm input whose backward sums are
+//     being fused) is read with 16-byte accesses straight into registers; for the result, lanes l and l ^ 8 trade
+//     one 16-byte half (one DPP rotation) so that a store instruction writes whole 128-byte lines;
 //   * all epilogue loads of a wave's 64 x 64 sub-tile are issued before the first one is used.
 //
 // Epilogue options (the same contract as conv_igemm.hip): per-channel BatchNorm statistics of the
@@ -74,29 +73,21 @@ struct ConvDmaParams {
     unsigned in2_bytes;
     int Ci2, pix_stride2;
     int taps[DMA_MAX_TAPS];            // offy (int8) | offx (int8) << 8 | widx (uint16) << 16
+#ifdef PDT_DMA_DIAG
+    int diag;                          // ablation build only (bench/diag): 1 no result stores, 2 weight DMA for a block's
+                                       // first tile only, 4 no MFMA, 8 operand DMA for the first tile only, 16 no epilogue loads
+#endif
 };
+#ifdef PDT_DMA_DIAG
+#define DIAG(bit) (p.diag & (bit))
+#else
+#define DIAG(bit) 0
+#endif
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_wave_base, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
-}
-
-// (lane group g = lane >> 4) x (register j) transpose of 4 x 4 dwords: afterwards v[j] of group g holds what
-// v[g] of group j held.
-__device__ __forceinline__ void transpose4(unsigned (&v)[4]) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        auto r = __builtin_amdgcn_permlane32_swap(v[j], v[j + 2], false, false);
-        v[j] = r[0];
-        v[j + 2] = r[1];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j += 2) {
-        auto r = __builtin_amdgcn_permlane16_swap(v[j], v[j + 1], false, false);
-        v[j] = r[0];
-        v[j + 1] = r[1];
-    }
 }
 
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
@@ -116,9 +107,35 @@ __device__ __forceinline__ int g1_swz(int row) {
     return BK == 64 ? ((row >> 1) & 7) : ((row >> 1) & 2);
 }
 
+// Which of a wave's 64 output channels an MFMA produces where is free: the lane that supplies operand row a of the
+// 16-row block j may read ANY weight row.  Row 16*(a >> 2) + 4*j + (a & 3) is the one that leaves lane group fq with
+// the 16 CONSECUTIVE channels 16*fq .. 16*fq + 15 of its pixel (register r of block j: channel 16*fq + 4*j + r), so
+// the epilogue needs no exchange between lanes to move 32 contiguous bytes per lane.  The weight tile's chunk swizzle
+// follows the fragment position (4*(row >> 4) + (row & 3) inside the 64-row block), not the row, to stay conflict-free.
+template <int BK>
+__device__ __forceinline__ int g1_swz_w(int row) {
+    return g1_swz<BK>(((row >> 4) & 3) * 4 + (row & 3));
+}
+
+// row_ror:8 inside each row of 16 lanes: lane l receives the value of lane l ^ 8
+__device__ __forceinline__ unsigned dpp_xor8(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false);   // (every lane has a source)
+}
+
+// max(x, 0) of both bf16 halves: as 16-bit integers, the negative values are exactly the patterns with the sign bit set
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_relu(unsigned v) {
+    union { unsigned u; s16x2_t h; } c;
+    c.u = v;
+    c.h = __builtin_elementwise_max(c.h, s16x2_t{0, 0});
+    return c.u;
+}
+
 // FOLD: the launch has a second operand and/or accumulator start values (its own instantiations, so the plain
 // kernels carry neither the extra scalar registers nor the extra LDS)
-template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD = false>
+// GEN: the generic epilogue (output rows scattered over a strided grid, or the addend at half resolution); the launches
+// whose output row is the GEMM row take the lean one (two instantiations: both epilogues in one kernel cost 60 registers)
+template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD = false, bool GEN = false>
 __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p) {
     constexpr int BM = 128, RB = BK * 2;
     constexpr int CH = BK / 8;                              // 16-byte chunks per LDS row
@@ -148,6 +165,10 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int frow = lane & 15, fq = lane >> 4;
+    // fast epilogue: byte offset of this lane's 32 bytes inside the wave tile (loads), and of its 16-byte piece of the
+    // pixel of lane frow & 7 after the exchange with lane frow ^ 8 (stores: (frow & 8) is the piece's 8 elements)
+    const unsigned ep_ld = (unsigned)(frow * p.N + fq * 16) * 2u;
+    const unsigned ep_st = (unsigned)((frow & 7) * p.N + fq * 16 + (frow & 8)) * 2u;
 
     const int n_tiles_n = p.N / BN;
     const int n_tiles_m = (p.M + BM - 1) / BM;
@@ -186,17 +207,24 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
             const int row = (wave * A_DMA + j) * RPI + d_row;
             int m = m0 + row;
             m = m < p.M ? m : p.M - 1;                       // rows past the end are computed and thrown away
-            unsigned b = (unsigned)m / (unsigned)HgWg, rem = (unsigned)m - b * (unsigned)HgWg;
-            unsigned y = rem / (unsigned)p.Wg, x = rem - y * (unsigned)p.Wg;
-            a_base[j] = (int)b * p.Hi * p.Wi;
-            a_y[j] = (int)y * p.IS;
-            a_x[j] = (int)x * p.IS;
+            if (FOLD) {
+                // (launcher: one tap at offset 0, IS == 1 and the grid is the input image: GEMM row m is input pixel m)
+                a_base[j] = m;
+                a_y[j] = 0;
+                a_x[j] = 0;
+            } else {
+                unsigned b = (unsigned)m / (unsigned)HgWg, rem = (unsigned)m - b * (unsigned)HgWg;
+                unsigned y = rem / (unsigned)p.Wg, x = rem - y * (unsigned)p.Wg;
+                a_base[j] = (int)b * p.Hi * p.Wi;
+                a_y[j] = (int)y * p.IS;
+                a_x[j] = (int)x * p.IS;
+            }
             a_sw[j] = (unsigned)((d_chunk ^ g1_swz<BK>(row)) * 16);
         }
 #pragma unroll
         for (int j = 0; j < B_DMA; ++j) {
             const int row = (wave * B_DMA + j) * RPI + d_row;
-            voff_b[j] = ((unsigned)(n0 + row) * (unsigned)p.wrow + (unsigned)((d_chunk ^ g1_swz<BK>(row)) * 8)) * 2u;
+            voff_b[j] = ((unsigned)(n0 + row) * (unsigned)p.wrow + (unsigned)((d_chunk ^ g1_swz_w<BK>(row)) * 8)) * 2u;
         }
     };
     // issue the DMA of the step under the cursor into stage ibuf and advance; false once every step was issued
@@ -213,6 +241,11 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
             wofs = (unsigned)(wi * p.Ci + c0) * 2u;
 #pragma unroll
             for (int j = 0; j < A_DMA; ++j) {
+                if (DIAG(8) && iv != (int)blockIdx.x) continue;
+                if (FOLD) {
+                    dma16(a_rsrc, As + (wave * A_DMA + j) * 1024, (unsigned)(a_base[j] * p.pix_stride + c0) * 2u + a_sw[j], 0u);
+                    continue;
+                }
                 const int iy = a_y[j] + oy, ix = a_x[j] + ox;
                 const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
                 const unsigned off = (unsigned)((a_base[j] + iy * p.Wi + ix) * p.pix_stride + c0) * 2u + a_sw[j];
@@ -220,16 +253,14 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
                 dma16(a_rsrc, As + (wave * A_DMA + j) * 1024, ok ? off : PDT_OOB_OFFSET, 0u);
             }
         } else {
-            // (launcher: IS == 1 and the grid is the input image, so a_base + a_y * Wi + a_x is the GEMM row)
             wofs = (unsigned)(p.T * p.Ci + c0) * 2u;
 #pragma unroll
-            for (int j = 0; j < A_DMA; ++j) {
-                const unsigned off = (unsigned)((a_base[j] + a_y[j] * p.Wi + a_x[j]) * p.pix_stride2 + c0) * 2u + a_sw[j];
-                dma16(a2_rsrc, As + (wave * A_DMA + j) * 1024, off, 0u);
-            }
+            for (int j = 0; j < A_DMA; ++j)
+                dma16(a2_rsrc, As + (wave * A_DMA + j) * 1024, (unsigned)(a_base[j] * p.pix_stride2 + c0) * 2u + a_sw[j], 0u);
         }
 #pragma unroll
-        for (int j = 0; j < B_DMA; ++j) dma16(w_rsrc, Bs + (wave * B_DMA + j) * 1024, voff_b[j], wofs);
+        for (int j = 0; j < B_DMA; ++j)
+            if (!(DIAG(2) && iv != (int)blockIdx.x)) dma16(w_rsrc, Bs + (wave * B_DMA + j) * 1024, voff_b[j], wofs);
         ibuf = ibuf + 1 == R ? 0 : ibuf + 1;
         // (kc + (second ? kdiff : 0), not second ? kc2 : kc: a conditional between two variables captured by reference
         // selects an ADDRESS, which keeps the closure in scratch memory and makes the cursor look divergent)
@@ -253,8 +284,8 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
             bf16x8 af[MI], bfr[NI];
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                const int row = wn * WTN + j * 16 + frow;
-                bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * RB + (((kk * 4 + fq) ^ g1_swz<BK>(row)) << 4));
+                const int row = wn * WTN + (frow >> 2) * 16 + j * 4 + (frow & 3);     // see g1_swz_w
+                bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * RB + (((kk * 4 + fq) ^ g1_swz_w<BK>(row)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -346,10 +377,10 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
         tile_origin(v, m0, n0);               // the tile computed now
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            // accumulator register r of lane group fq: channel n0 + wn*WTN + j*16 + fq*4 + r
+            // accumulator register r of lane group fq: channel n0 + wn*WTN + fq*16 + j*4 + r
             f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (bias_in_lds) b0 = *reinterpret_cast<const f32x4*>(bias_lds + n0 + wn * WTN + j * 16 + fq * 4);
-            else if (has_bias) b0 = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * WTN + j * 16 + fq * 4);
+            if (bias_in_lds) b0 = *reinterpret_cast<const f32x4*>(bias_lds + n0 + wn * WTN + fq * 16 + j * 4);
+            else if (has_bias) b0 = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * WTN + fq * 16 + j * 4);
 #pragma unroll
             for (int i = 0; i < MI; ++i) acc[i][j] = b0;
         }
@@ -363,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
             // ... and so has every other wave's; all waves are also done reading the stage refilled next
             __builtin_amdgcn_s_barrier();
             if (issuing) issuing = issue_next();
-            compute(buf);
+            if (!DIAG(4)) compute(buf);
             buf = buf + 1 == R ? 0 : buf + 1;
         }
         const int vn = v + gridDim.x;
@@ -379,11 +410,160 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
             stat_n0 = n0;
             load_consts(nb);
         }
+        // LEAN EPILOGUE (output row == GEMM row, addend at full resolution: every 1x1 / stride-1 launch and every
+        // stride-1 3x3 one): the wave tile's operands are addressed through buffer descriptors based at the
+        // wave tile's origin, with a loop-invariant per-lane offset and the row group as SCALAR offset -- no per-row
+        // index arithmetic, no 64-bit address math, no predicates; ReLU and the sign mask work on the packed bf16
+        // pairs.  The epilogue's vector instructions are what bounds the one- and two-K-step launches (with every load
+        // and store switched off the 64 -> 256 channel block tail at 56 x 56 still took 45 % of its time), so their
+        // count is what this path is about.
+        constexpr int EG = (BSTAT && MI > 2) ? 2 : MI;
+        const bool has_addend = p.addend != nullptr && !DIAG(16), has_mask = p.mask_bits != nullptr && !DIAG(16);
+        if constexpr (!GEN) {
+            const int row0 = m0 + wm * WTM;                                  // wave-uniform
+            const size_t e0 = (size_t)row0 * (size_t)p.N + (size_t)(n0 + wn * WTN);
+            // the descriptors end with the tensor: loads of rows past M return zeros, their stores are dropped
+            const int rows_left = p.M - row0;
+            const bool partial = rows_left < WTM;
+            const unsigned span = rows_left <= 0 ? 0u : (unsigned)((partial ? rows_left : WTM) * p.N * 2);
+            const int row16 = 16 * p.N * 2;
+            const __amdgpu_buffer_rsrc_t o_rs = make_rsrc(p.out + e0, span);
+            const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(has_addend ? p.addend + e0 : nullptr, has_addend ? span : 0u);
+            const __amdgpu_buffer_rsrc_t y_rs = make_rsrc(BSTAT ? p.bstat_y + e0 : nullptr, BSTAT ? span : 0u);
+            const __amdgpu_buffer_rsrc_t m_rs = make_rsrc(has_mask ? p.mask_bits + (e0 >> 3) : nullptr, has_mask ? span >> 4 : 0u);
+            const bool relu = FOLD && !BSTAT && p.relu_out, want_bits = FOLD && !BSTAT && p.bits_out != nullptr;
+            const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(want_bits ? p.bits_out + (e0 >> 3) : nullptr, want_bits ? span >> 4 : 0u);
+#pragma unroll
+            for (int i0 = 0; i0 < MI; i0 += EG) {
+                u32x4 yv[BSTAT ? EG : 1][2], av[EG][2];
+                unsigned mb[EG];
+#pragma unroll
+                for (int e = 0; e < EG; ++e) {
+                    const int so = (i0 + e) * row16;
+                    if (BSTAT) {
+                        yv[e][0] = __builtin_amdgcn_raw_buffer_load_b128(y_rs, (int)ep_ld, so, 0);
+                        yv[e][1] = __builtin_amdgcn_raw_buffer_load_b128(y_rs, (int)ep_ld + 16, so, 0);
+                    }
+                    if (has_addend) {                                       // (non-temporal: last use of the tensor)
+                        av[e][0] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)ep_ld, so, 2);
+                        av[e][1] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)ep_ld + 16, so, 2);
+                    }
+                    if (has_mask) mb[e] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(m_rs, (int)(ep_ld >> 4), so >> 4, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < EG; ++e) {
+                    const int i = i0 + e;
+                    const int so = i * row16;
+                    float val[16];
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) val[j * 4 + r] = acc[i][j][r];
+                    if (has_addend) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) {
+                                const unsigned a = av[e][h][d];
+                                const int k = h * 8 + d * 2;
+                                val[k] += bf_lo(a);
+                                val[k + 1] += bf_hi(a);
+                            }
+                    }
+                    unsigned pk[8];                                         // the bf16 pairs that will be stored
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) pk[d] = pack2(val[d * 2], val[d * 2 + 1]);
+                    if (has_mask) {
+#pragma unroll
+                        for (int d = 0; d < 8; ++d) {
+                            const unsigned lo = (unsigned)__builtin_amdgcn_sbfe((int)mb[e], 2 * d, 1);
+                            const unsigned hi = (unsigned)__builtin_amdgcn_sbfe((int)mb[e], 2 * d + 1, 1);
+                            pk[d] &= (lo & 0xffffu) | (hi & ~0xffffu);           // (one bit-field insert)
+                        }
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int d = 0; d < 8; ++d) pk[d] = pk_relu(pk[d]);
+                    }
+                    if (want_bits) {
+                        // after the clamp a half is 0x0000 .. 0x7fff (or a NaN pattern >= 0x7f81): adding 0x7fff sets bit 15
+                        // of exactly the positive ones, with no carry into the upper half
+                        unsigned m16 = 0;
+#pragma unroll
+                        for (int d = 0; d < 8; ++d) {
+                            const unsigned t = (relu ? pk[d] : (pk[d] & 0x7fff7fffu)) + 0x7fff7fffu;
+                            const unsigned two = __builtin_amdgcn_ubfe(t, 15, 1) | (__builtin_amdgcn_ubfe(t, 31, 1) << 1);
+                            m16 |= two << (2 * d);
+                        }
+                        if (!relu) {                                         // (not used today: signs would have to count)
+#pragma unroll
+                            for (int d = 0; d < 8; ++d) {
+                                const unsigned neg = __builtin_amdgcn_ubfe(pk[d], 15, 1) | (__builtin_amdgcn_ubfe(pk[d], 31, 1) << 1);
+                                m16 &= ~(neg << (2 * d));
+                            }
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b16((short)m16, b_rs, (int)(ep_ld >> 4), so >> 4, 0);
+                    }
+                    auto add_stats = [&]() {
+                        // rows past M (last tile only) were computed from a repeated input row: keep them out of the sums
+                        if (partial && (BSTAT || want_stats) && i * 16 + frow >= rows_left) return;
+                        if (BSTAT) {
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                                for (int d = 0; d < 4; ++d) {
+                                    const unsigned yy2 = yv[e][h][d], pp = pk[h * 4 + d];
+                                    const int k = h * 8 + d * 2;
+                                    const float y0 = bf_lo(yy2), y1 = bf_hi(yy2);
+                                    float d0 = bf_lo(pp), d1 = bf_hi(pp);
+                                    if (bwd_mask) {
+                                        d0 = (y0 * msc[k] + msh[k]) > 0.0f ? d0 : 0.0f;
+                                        d1 = (y1 * msc[k + 1] + msh[k + 1]) > 0.0f ? d1 : 0.0f;
+                                    }
+                                    s0[k] += d0;
+                                    s1[k] += d0 * (y0 - ctr[k]);
+                                    s0[k + 1] += d1;
+                                    s1[k + 1] += d1 * (y1 - ctr[k + 1]);
+                                }
+                        } else if (want_stats) {
+#pragma unroll
+                            for (int d = 0; d < 8; ++d) {
+                                const float a = bf_lo(pk[d]) - ctr[2 * d], b = bf_hi(pk[d]) - ctr[2 * d + 1];
+                                s0[2 * d] += a;
+                                s1[2 * d] += a * a;
+                                s0[2 * d + 1] += b;
+                                s1[2 * d + 1] += b * b;
+                            }
+                        }
+                    };
+                    auto store_result = [&]() {
+                        // whole 128-byte lines per store instruction: see the generic path below
+                        const bool up = (frow & 8) != 0;
+                        u32x4 first, second;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const unsigned got = dpp_xor8(up ? pk[d] : pk[4 + d]);
+                            first[d] = up ? got : pk[d];
+                            second[d] = up ? pk[4 + d] : got;
+                        }
+                        if (!DIAG(1)) {
+                            __builtin_amdgcn_raw_buffer_store_b128(first, o_rs, (int)ep_st, so, 2);
+                            __builtin_amdgcn_raw_buffer_store_b128(second, o_rs, (int)ep_st, so + (row16 >> 1), 2);
+                        }
+                    };
+                    if (BSTAT) {
+                        store_result();
+                        add_stats();
+                    } else {
+                        add_stats();
+                        store_result();
+                    }
+                }
+            }
+        } else {
         // Epilogue operands of EG row groups first, so they are all in flight together: all MI of them, except with
         // the backward-sums epilogue on a 64-row wave tile, where four groups of loads on top of the 80 registers of
         // sums and per-channel constants would not fit 256 VGPRs -- two passes of two groups there.
-        constexpr int EG = (BSTAT && MI > 2) ? 2 : MI;
-        const bool has_addend = p.addend != nullptr, has_mask = p.mask_bits != nullptr;
 #pragma unroll
         for (int i0 = 0; i0 < MI; i0 += EG) {
         size_t oidx[EG];
@@ -432,36 +612,26 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
 #pragma unroll
         for (int e = 0; e < EG; ++e) {
             const int i = i0 + e;
-            // bf16 pairs: register j of lane group fq holds channels j*16 + fq*4 + {0,1} / {2,3}
-            unsigned lo[4], hi[4];
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                lo[j] = pack2(acc[i][j][0], acc[i][j][1]);
-                hi[j] = pack2(acc[i][j][2], acc[i][j][3]);
-            }
-            transpose4(lo);
-            transpose4(hi);
-            // now register j of lane group g: channels g*16 + j*4 + {0,1} (lo) / {2,3} (hi)
+            // register r of block j holds channel 16*fq + 4*j + r of this lane's pixel (see g1_swz_w); the value (plus the
+            // addend) is rounded to bf16 ONCE, and everything after that works on what will be stored
             float val[16];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                val[j * 4 + 0] = bf_lo(lo[j]);
-                val[j * 4 + 1] = bf_hi(lo[j]);
-                val[j * 4 + 2] = bf_lo(hi[j]);
-                val[j * 4 + 3] = bf_hi(hi[j]);
-            }
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) val[j * 4 + r] = acc[i][j][r];
             if (has_addend) {
-                // the sum is rounded to bf16 like a separate add pass would (and like conv_igemm.hip does)
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         const unsigned a = av[e][h][d];
                         const int k = h * 8 + d * 2;
-                        val[k] = bf2f(f2bf(val[k] + bf_lo(a)));
-                        val[k + 1] = bf2f(f2bf(val[k + 1] + bf_hi(a)));
+                        val[k] += bf_lo(a);
+                        val[k + 1] += bf_hi(a);
                     }
             }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) val[k] = bf2f(f2bf(val[k]));
             if (has_mask) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) val[k] = ((mb[e] >> k) & 1u) ? val[k] : 0.0f;
@@ -476,43 +646,76 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
                 for (int k = 0; k < 16; ++k) m16 |= (val[k] > 0.0f ? 1u : 0u) << k;
                 *reinterpret_cast<unsigned short*>(p.bits_out + (oidx[e] >> 3)) = (unsigned short)m16;
             }
-            if (live[e]) {
-                u32x4 o0, o1;
+            // (order chosen per variant by the register allocation it leads to: the backward-sums variants spill otherwise)
+            auto add_stats = [&]() {
+    if (live[e]) {
+                    if (BSTAT) {
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    o0[d] = pack2(val[d * 2], val[d * 2 + 1]);
-                    o1[d] = pack2(val[8 + d * 2], val[8 + d * 2 + 1]);
-                }
-                u32x4* op = reinterpret_cast<u32x4*>(p.out + oidx[e]);
-                __builtin_nontemporal_store(o0, op);
-                __builtin_nontemporal_store(o1, op + 1);
-                if (BSTAT) {
+                        for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) {
-                            const unsigned yy2 = yv[e][h][d];
-                            const int k = h * 8 + d * 2;
-                            float y0 = bf_lo(yy2), y1 = bf_hi(yy2);
-                            float d0 = val[k], d1 = val[k + 1];
-                            if (bwd_mask) {
-                                d0 = (y0 * msc[k] + msh[k]) > 0.0f ? d0 : 0.0f;
-                                d1 = (y1 * msc[k + 1] + msh[k + 1]) > 0.0f ? d1 : 0.0f;
+                            for (int d = 0; d < 4; ++d) {
+                                const unsigned yy2 = yv[e][h][d];
+                                const int k = h * 8 + d * 2;
+                                float y0 = bf_lo(yy2), y1 = bf_hi(yy2);
+                                float d0 = val[k], d1 = val[k + 1];
+                                if (bwd_mask) {
+                                    d0 = (y0 * msc[k] + msh[k]) > 0.0f ? d0 : 0.0f;
+                                    d1 = (y1 * msc[k + 1] + msh[k + 1]) > 0.0f ? d1 : 0.0f;
+                                }
+                                s0[k] += d0;
+                                s1[k] += d0 * (y0 - ctr[k]);
+                                s0[k + 1] += d1;
+                                s1[k + 1] += d1 * (y1 - ctr[k + 1]);
                             }
-                            s0[k] += d0;
-                            s1[k] += d0 * (y0 - ctr[k]);
-                            s0[k + 1] += d1;
-                            s1[k + 1] += d1 * (y1 - ctr[k + 1]);
-                        }
-                } else if (want_stats) {
+                    } else if (want_stats) {
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const float d = val[k] - ctr[k];
-                        s0[k] += d;
-                        s1[k] += d * d;
+                        for (int k = 0; k < 16; ++k) {
+                            const float d = val[k] - ctr[k];
+                            s0[k] += d;
+                            s1[k] += d * d;
+                        }
                     }
                 }
+            };
+            auto store_result = [&]() {
+    {
+                    // Result stores in whole 128-byte lines: lane (fq, frow) holds bytes [32 fq, 32 fq + 32) of its pixel's
+                    // 128-byte segment; lanes frow and frow ^ 8 trade one 16-byte half (a rotation by 8 inside the row of 16
+                    // lanes), after which the eight lanes (fq, frow & 8) hold the eight 16-byte pieces of ONE pixel: a store
+                    // instruction writes 8 full lines instead of 16 rows x 4 pieces of 16 bytes at a stride of 32 (streaming
+                    // stores in that split pattern reach 2.2 TB/s, in whole lines 5.2: bench/diag/store_pattern.hip).
+                    u32x4 o0, o1;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        o0[d] = pack2(val[d * 2], val[d * 2 + 1]);
+                        o1[d] = pack2(val[8 + d * 2], val[8 + d * 2 + 1]);
+                    }
+                    const bool up = (frow & 8) != 0;
+                    u32x4 got;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) got[d] = dpp_xor8(up ? o0[d] : o1[d]);
+                    // the partner's output element (a multiple of 16, so bit 0 carries "row past the end") as a signed
+                    // 32-bit distance from this lane's: the two pixels are at most a few images apart
+                    const unsigned mine = (unsigned)oidx[e] | (live[e] ? 0u : 1u);
+                    const unsigned other = dpp_xor8(mine);
+                    const int dist = (int)((other & ~1u) - (unsigned)oidx[e]);
+                    // piece 2 fq + (frow >> 3) of the pixel of lane frow & 7 (first) and of lane 8 + (frow & 7) (second)
+                    const bool ok_first = !((up ? other : mine) & 1u), ok_second = !((up ? mine : other) & 1u);
+                    bf16* o_first = p.out + oidx[e] + (up ? dist + 8 : 0);
+                    bf16* o_second = p.out + oidx[e] + (up ? 8 : dist);
+                    const u32x4 v_first = up ? got : o0, v_second = up ? o1 : got;
+                    if (ok_first && !DIAG(1)) __builtin_nontemporal_store(v_first, reinterpret_cast<u32x4*>(o_first));
+                    if (ok_second && !DIAG(1)) __builtin_nontemporal_store(v_second, reinterpret_cast<u32x4*>(o_second));
+                }
+            };
+            if (BSTAT) {
+                store_result();
+                add_stats();
+            } else {
+                add_stats();
+                store_result();
             }
+        }
         }
         }
         if (!more) break;
@@ -521,28 +724,43 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
     if (want_stats && stat_n0 >= 0) flush_stats(stat_n0);
 }
 
-template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD = false>
-static int g1_resident_blocks() {
+template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD, bool GEN>
+static int g1_resident_blocks_of() {
     static int cached = 0;
     if (cached > 0) return cached;
     int per_cu = 0, dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 512;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_dma_kernel<BN, WM, WN, BK, R, BSTAT, FOLD>, 256, 0) != hipSuccess || per_cu <= 0)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_dma_kernel<BN, WM, WN, BK, R, BSTAT, FOLD, GEN>, 256, 0) != hipSuccess || per_cu <= 0)
         per_cu = 2;
     cached = per_cu * cus;
     return cached;
 }
 
 template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD = false>
-static int g1_launch(const ConvDmaParams& p, hipStream_t s) {
+static int g1_resident_blocks() {
+    return g1_resident_blocks_of<BN, WM, WN, BK, R, BSTAT, FOLD, false>();
+}
+
+template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD, bool GEN>
+static int g1_launch_of(const ConvDmaParams& p, hipStream_t s) {
     long long nwg = (long long)((p.M + 127) / 128) * (p.N / BN);
     if (nwg <= 0 || nwg > 0x7fffffffLL) return -2;
-    long long grid = g1_resident_blocks<BN, WM, WN, BK, R, BSTAT, FOLD>();
+    long long grid = g1_resident_blocks_of<BN, WM, WN, BK, R, BSTAT, FOLD, GEN>();
     if (grid > nwg) grid = nwg;
     if (g_pdt_deterministic && grid > p.nrep) grid = p.nrep;      // one statistics row per workgroup
-    hipLaunchKernelGGL((conv_dma_kernel<BN, WM, WN, BK, R, BSTAT, FOLD>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_dma_kernel<BN, WM, WN, BK, R, BSTAT, FOLD, GEN>), dim3((unsigned)grid), dim3(256), 0, s, p);
     return pdt_launch_status();
+}
+
+template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD = false>
+static int g1_launch(const ConvDmaParams& p, hipStream_t s) {
+    // the lean epilogue wants output row == GEMM row and a full-resolution addend (always true with a second operand /
+    // start values: the launcher admits only the plain 1x1 geometry there)
+    if (!FOLD && (!p.simple_out || p.addend_half)) {
+        if constexpr (!FOLD) return g1_launch_of<BN, WM, WN, BK, R, BSTAT, false, true>(p, s);
+    }
+    return g1_launch_of<BN, WM, WN, BK, R, BSTAT, FOLD, false>(p, s);
 }
 
 // tile: 0 = auto (3 when N is a multiple of 128, else 4); 3 = 128 x 128 with K slices of 64 and two stages, 4 = 128 x 64
@@ -572,9 +790,11 @@ PDT_API int pdt_conv_dma_ex(const void* in, const void* wgt, void* out, const vo
     if (M <= 0) return 0;
     if (!in2) Ci2 = 0;
     if (M >= 0x7fffffffLL || N < 64 || N % 64 != 0 || wrow < T * Ci + Ci2) return -4;
-    if (in2) {
-        // the second operand is addressed by GEMM row: needs the plain 1x1 / stride 1 geometry
+    if (in2 || bias) {
+        // these instantiations address their operands by GEMM row: the plain 1x1 / stride 1 geometry only
         if (tile == 5 || T != 1 || offy[0] != 0 || offx[0] != 0 || IS != 1 || Hg != Hi || Wg != Wi) return -11;
+    }
+    if (in2) {
         if (Ci2 < 64 || Ci2 % 64 != 0 || pix_stride2 < Ci2 || pix_stride2 % 8 != 0) return -11;
         if (M * (long long)pix_stride2 * 2 >= 0x7fff0000LL) return -7;
     }
@@ -606,6 +826,9 @@ PDT_API int pdt_conv_dma_ex(const void* in, const void* wgt, void* out, const vo
     p.nrep = pdt_nrep();
     p.in2 = (const bf16*)in2; p.bias = bias; p.Ci2 = Ci2; p.pix_stride2 = in2 ? pix_stride2 : 0;
     p.relu_out = relu_out ? 1 : 0; p.bits_out = (unsigned char*)bits_out;
+#ifdef PDT_DMA_DIAG
+    { const char* e = getenv("PDT_DMA_DIAG"); p.diag = e ? atoi(e) : 0; }
+#endif
     p.in2_bytes = in2 ? (unsigned)(M * (long long)pix_stride2 * 2) : 0u;
     {
         long long images = M / ((long long)Hg * Wg);

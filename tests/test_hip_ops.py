@@ -354,7 +354,10 @@ def test_packed_relu_mask_roundtrip(hip, device, C, H, stride, k):
     dy = rnd(B, Ho, Ho, Co, device=device)
     a = hip.conv_dgrad(dy, w, wt, tuple(out.shape), k, k, stride, pad, addend=res, relu_mask=out)
     b = hip.conv_dgrad(dy, w, wt, tuple(out.shape), k, k, stride, pad, addend=res, relu_bits=bits)
-    assert torch.equal(a, b)
+    # (the tensor form runs on the register-staged kernel, which rounds the convolution result to bf16 before it adds;
+    # the packed form rounds the sum once: zeros where the mask is off, values within one rounding)
+    off = ~(out > 0)
+    assert bool((a[off] == 0).all()) and bool((b[off] == 0).all()) and rel_err(a, b) < 8e-3
     c = ref.conv_dgrad(dy, w, None, tuple(out.shape), k, k, stride, pad, addend=res, relu_bits=bits)
     assert rel_err(b, c) < 1.5e-2
     # with fused backward statistics the mask is accepted in packed form only
@@ -362,7 +365,7 @@ def test_packed_relu_mask_roundtrip(hip, device, C, H, stride, k):
     d = hip.conv_dgrad(dy, w, wt, tuple(out.shape), k, k, stride, pad, addend=res, relu_bits=bits,
                        bwd_stats=(y, mean, None, None, ref.MASK_NONE))
     hip.bn_bwd_reduce(d, y, mean, torch.ones(C, device=device), None, None, None, ref.MASK_NONE, prereduced=True)
-    assert torch.equal(d, a)
+    assert torch.equal(d, b)
     with pytest.raises(ValueError):
         hip.conv_dgrad(dy, w, wt, tuple(out.shape), k, k, stride, pad, addend=res, relu_mask=out,
                        bwd_stats=(y, mean, None, None, ref.MASK_NONE))
