@@ -17,10 +17,11 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = [(0, "full kernel"), (1, "no result stores"), (2, "weights loaded once per workgroup"), (4, "no MFMA"),
             (16, "no epilogue loads"), (1 | 16, "no stores, no epilogue loads"), (8 | 2, "operands loaded once"),
-            (1 | 2 | 8 | 16, "MFMA + epilogue arithmetic only")]
+            (1 | 2 | 8 | 16, "MFMA + epilogue arithmetic only"), (32, "no epilogue"), (32 | 2 | 8, "main loop only, operands loaded once"),
+            (32 | 2 | 8 | 4, "main loop without MFMA, operands loaded once")]
 
 
-def child(batch: int) -> None:
+def child(batch: int, tile: int) -> None:
     import torch
     from pytorch_distributed_training_amd.ops import hip
 
@@ -49,8 +50,8 @@ def child(batch: int) -> None:
         y = torch.empty(batch, h, h, n, dtype=torch.bfloat16, device=dev)
         gb_plain = (a.numel() + y.numel()) * 2 / 1e9
         gb_tail = (a.numel() + 2 * y.numel() + y.numel() // 16) * 2 / 1e9
-        t_plain = timeit(lambda: hip.conv_fprop(a, w4, 1, 1, 1, 0, out=y))
-        t_tail = timeit(lambda: hip.conv_fprop_fused_tail(a, wf, shift, addend=x, bits_out=bits, out=y))
+        t_plain = timeit(lambda: hip.conv_fprop(a, w4, 1, 1, 1, 0, out=y, tile=-tile))
+        t_tail = timeit(lambda: hip.conv_fprop_fused_tail(a, wf, shift, addend=x, bits_out=bits, out=y, tile=tile))
         out.append(f"{c}->{n}@{h}: plain {t_plain:7.1f} us {gb_plain / t_plain * 1e3:5.2f} TB/s | "
                    f"tail+addend {t_tail:7.1f} us {gb_tail / t_tail * 1e3:5.2f} TB/s")
     print(" || ".join(out), flush=True)
@@ -60,13 +61,18 @@ def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--child", action="store_true")
+    ap.add_argument("--tile", type=int, default=0, help="tile of the LDS-DMA kernel (3 = 128 x 128, 4 = 128 x 64)")
+    ap.add_argument("--variants", type=str, default="", help="comma-separated switch values (default: all)")
     args = ap.parse_args()
     if args.child:
-        child(args.batch)
+        child(args.batch, args.tile)
         return 0
+    only = {int(v) for v in args.variants.split(",") if v}
     for bits, name in VARIANTS:
+        if only and bits not in only:
+            continue
         env = dict(os.environ, PDT_DMA_DIAG=str(bits))
-        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--batch", str(args.batch)], env=env,
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--batch", str(args.batch), "--tile", str(args.tile)], env=env,
                              capture_output=True, text=True, timeout=170)
         line = [ln for ln in res.stdout.splitlines() if "->" in ln]
         print(f"{bits:3d} {name:36s} {line[-1] if line else 'FAILED: ' + res.stderr[-300:]}", flush=True)

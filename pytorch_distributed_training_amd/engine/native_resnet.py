@@ -948,7 +948,7 @@ class NativeResNet:
         dy_first = None
         s0 = None
         if g_prereduced == "s0":
-            s0 = ops.grad_sums(g.shape[-1], self.device)[0]
+            s0 = ops.grad_sums(g.shape[-1], self.device)
             g_prereduced = False
         for i in range(last, -1, -1):
             u = b.units[i]

@@ -41,6 +41,7 @@
 // the result at zero and write its packed sign mask: with BatchNorm's scale folded into the weights and its shift
 // as start value, a block tail  relu(bn(conv(a)) [+ bn(conv_shortcut(x))] [+ x])  is this kernel's epilogue.
 #include "common.h"
+#include <type_traits>
 
 #define DMA_MAX_TAPS 52
 #define DMA_MAX_BIAS 512
@@ -70,12 +71,13 @@ struct ConvDmaParams {
     const float* bias;                 // [N] start value of the accumulators (may be null)
     unsigned char* bits_out;           // packed [out > 0] of the stored result, one bit per element (may be null)
     int relu_out;                      // clamp the result at zero before it is stored
+    int sums_only;                     // stat_acc receives plain per-channel sums of the result (row 1 is not defined)
     unsigned in2_bytes;
     int Ci2, pix_stride2;
     int taps[DMA_MAX_TAPS];            // offy (int8) | offx (int8) << 8 | widx (uint16) << 16
 #ifdef PDT_DMA_DIAG
     int diag;                          // ablation build only (bench/diag): 1 no result stores, 2 weight DMA for a block's
-                                       // first tile only, 4 no MFMA, 8 operand DMA for the first tile only, 16 no epilogue loads
+                                       // first tile only, 4 no MFMA, 8 operand DMA for the first tile only, 16 no epilogue loads, 32 no epilogue
 #endif
 };
 #ifdef PDT_DMA_DIAG
@@ -135,8 +137,15 @@ __device__ __forceinline__ unsigned pk_relu(unsigned v) {
 // kernels carry neither the extra scalar registers nor the extra LDS)
 // GEN: the generic epilogue (output rows scattered over a strided grid, or the addend at half resolution); the launches
 // whose output row is the GEMM row take the lean one (two instantiations: both epilogues in one kernel cost 60 registers)
-template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD = false, bool GEN = false>
+// PF: the epilogue's operands (addend, packed mask) of tile t+1 are requested while tile t is multiplied and stay in flight
+// under its epilogue (a second register set; requested by inline assembly so that the compiler's own waits do not drain
+// them, complete at the next tile's first wait).  The one- and two-K-step launches otherwise wait for these loads with
+// nothing else to do: per tile their latency was exposed in full.  Only for the lean epilogue without the backward-sums
+// operands, and the statistics of such a launch are plain per-channel sums (no centre, no squares): that is what the
+// register budget allows next to 64 accumulators.
+template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD = false, bool GEN = false, bool PF = false>
 __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p) {
+    static_assert(!PF || (!BSTAT && !GEN && R == 2), "the prefetching variant: lean epilogue, no backward-sums operands, ring of two");
     constexpr int BM = 128, RB = BK * 2;
     constexpr int CH = BK / 8;                              // 16-byte chunks per LDS row
     constexpr int RPI = 64 / CH;                            // LDS rows one DMA instruction fills (1 KiB)
@@ -199,9 +208,12 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
     int a_base[A_DMA], a_y[A_DMA], a_x[A_DMA];                 // image base pixel and grid coordinates * IS of this lane's rows
     unsigned a_sw[A_DMA], voff_b[B_DMA];
     int iv = blockIdx.x, it = 0, ic = 0, ibuf = 0;            // gridDim.x <= nwg (launcher); cursor = (tile, tap, channel slice)
+    int i_m0 = 0, i_n0 = 0;                                   // origin of the cursor's tile
     auto setup_issue_tile = [&]() {
         int m0, n0;
         tile_origin(iv, m0, n0);
+        i_m0 = m0;
+        i_n0 = n0;
 #pragma unroll
         for (int j = 0; j < A_DMA; ++j) {
             const int row = (wave * A_DMA + j) * RPI + d_row;
@@ -302,11 +314,17 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
 
     // per-lane statistics of the 16 channels this lane owns after the transpose (kept across the tiles of a
     // workgroup while they cover the same channels), and the per-channel constants they need
-    const bool want_stats = p.stat_acc != nullptr;
+    // (a launch with a second operand / start values and no backward-sums epilogue never carries statistics: launcher)
+    constexpr bool NOSTATS = FOLD && !BSTAT;
+    const bool want_stats = !NOSTATS && p.stat_acc != nullptr;
     const bool bwd_mask = BSTAT && p.bstat_scale != nullptr;
-    float s0[16], s1[16], ctr[16], msc[BSTAT ? 16 : 1], msh[BSTAT ? 16 : 1];
+    constexpr int NS1 = (PF || NOSTATS) ? 1 : 16;             // (PF: plain sums only)
+    constexpr int NS0 = NOSTATS ? 1 : 16;
+    float s0[NS0], s1[NS1], ctr[NS1], msc[BSTAT ? 16 : 1], msh[BSTAT ? 16 : 1];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { s0[k] = 0.f; s1[k] = 0.f; ctr[k] = 0.f; }
+    for (int k = 0; k < NS0; ++k) s0[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NS1; ++k) { s1[k] = 0.f; ctr[k] = 0.f; }
     int stat_n0 = -1;
 
     // Fold the per-lane partial sums of a channel tile into the replicated accumulator: across the 16 lanes
@@ -315,19 +333,20 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
     // workgroup -- hundreds of workgroups finish together and all add into the same few hundred addresses.
     // Called by every thread of the workgroup at the same point (the condition is workgroup-uniform).
     auto flush_stats = [&](int n0) {
+        if constexpr (NOSTATS) return;
         float mine0 = 0.f, mine1 = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            float a = s0[k], b = s1[k];
+            float a = s0[NOSTATS ? 0 : k], b = PF ? 0.f : s1[NS1 == 1 ? 0 : k];
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) {
                 a += __shfl_xor(a, off, 64);
-                b += __shfl_xor(b, off, 64);
+                if (!PF) b += __shfl_xor(b, off, 64);
             }
             mine0 = frow == k ? a : mine0;          // lane (fq, frow) keeps channel fq*16 + frow
             mine1 = frow == k ? b : mine1;
-            s0[k] = 0.f;
-            s1[k] = 0.f;
+            s0[NOSTATS ? 0 : k] = 0.f;
+            if (!PF) s1[NS1 == 1 ? 0 : k] = 0.f;
         }
         red[(wave * 2 + 0) * 64 + lane] = mine0;
         red[(wave * 2 + 1) * 64 + lane] = mine1;
@@ -343,17 +362,80 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
         __syncthreads();
     };
     auto load_consts = [&](int nb) {
+        if constexpr (PF || NOSTATS) return;
         const float* center = BSTAT ? p.bstat_mean : p.stat_shift;
 #pragma unroll
         for (int k = 0; k < 16; k += 4) {
             f32x4 c = center ? *reinterpret_cast<const f32x4*>(center + nb + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-            ctr[k] = c[0]; ctr[k + 1] = c[1]; ctr[k + 2] = c[2]; ctr[k + 3] = c[3];
+            if constexpr (NS1 == 16) { ctr[k] = c[0]; ctr[k + 1] = c[1]; ctr[k + 2] = c[2]; ctr[k + 3] = c[3]; }
             if (BSTAT) {
                 f32x4 a = bwd_mask ? *reinterpret_cast<const f32x4*>(p.bstat_scale + nb + k) : f32x4{0.f, 0.f, 0.f, 0.f};
                 f32x4 b = bwd_mask ? *reinterpret_cast<const f32x4*>(p.bstat_shift + nb + k) : f32x4{1.f, 1.f, 1.f, 1.f};
                 msc[k] = a[0]; msc[k + 1] = a[1]; msc[k + 2] = a[2]; msc[k + 3] = a[3];
                 msh[k] = b[0]; msh[k + 1] = b[1]; msh[k + 2] = b[2]; msh[k + 3] = b[3];
             }
+        }
+    };
+
+    // ---- PF: the two register sets of the epilogue's operands and the requests that fill the second one
+    constexpr int PMI = PF ? MI : 1;
+    u32x4 cav[PMI][2], nav[PMI][2];                            // addend: this tile's / the next tile's
+    unsigned cmb[PMI], nmb[PMI];                               // packed mask words
+    const bool pf_addend = PF && p.addend != nullptr && !DIAG(16), pf_mask = PF && p.mask_bits != nullptr && !DIAG(16);
+    auto issue_epilogue_loads = [&](int m0, int n0, bool live) {
+        // Descriptors based at each row group of the wave tile and ending with the tensor (an absent operand: zero records, the
+        // loads return zeros without touching memory, so the number of requests per tile is a constant; the same after
+        // the workgroup's last tile: the requests are issued unconditionally, see the tile loop).  They are
+        // assembled by hand because the assembly statement wants them as four scalar registers.
+        const int row0 = m0 + wm * WTM;
+        const unsigned long long e0 = (unsigned long long)row0 * (unsigned)p.N + (unsigned)(n0 + wn * WTN);
+        const int rows_left = live ? p.M - row0 : 0;
+        const unsigned long long a_addr = (unsigned long long)p.addend + e0 * 2ull;
+        const unsigned long long m_addr = (unsigned long long)p.mask_bits + (e0 >> 3);
+        const int row16 = 16 * p.N * 2;
+        const unsigned bit_off = ep_ld >> 4;
+#pragma unroll
+        for (int e = 0; e < PMI; ++e) {
+            // (the row group's offset is part of the descriptor's base: the range check never sees a scalar offset)
+            int have = rows_left - e * 16;
+            have = have < 0 ? 0 : (have > 16 ? 16 : have);
+            const unsigned nrec = (unsigned)(have * p.N * 2);
+            const unsigned long long a_e = a_addr + (unsigned)(e * row16), m_e = m_addr + (unsigned)((e * row16) >> 4);
+            const u32x4 a_desc = {(unsigned)a_e, (unsigned)(a_e >> 32) & 0xffffu, pf_addend ? nrec : 0u, 0x00020000u};
+            const u32x4 m_desc = {(unsigned)m_e, (unsigned)(m_e >> 32) & 0xffffu, pf_mask ? nrec >> 4 : 0u, 0x00020000u};
+            // (s_nop 4: the scalar registers may have been written by the instructions just before)
+            asm volatile(
+                "s_nop 4\n\t"
+                "buffer_load_dwordx4 %0, %3, %4, 0 offen nt\n\t"
+                "buffer_load_dwordx4 %1, %3, %4, 0 offen offset:16 nt\n\t"
+                "buffer_load_ushort %2, %5, %6, 0 offen"
+                : "=&v"(nav[e][0]), "=&v"(nav[e][1]), "=&v"(nmb[e])
+                : "v"(ep_ld), "s"(a_desc), "v"(bit_off), "s"(m_desc)
+                : "memory");
+        }
+    };
+    // The second set has landed once this returns: the wait leaves the YOUNGER operations in flight (the result stores
+    // of the tile that just ended, ``younger`` of them; the counter retires in issue order), and it names the set's
+    // registers, so no instruction that reads them can be scheduled above it.  Then the sets change roles.
+    auto take_epilogue_loads = [&](auto younger_tag) {
+        static_assert(PMI == 1 || PMI == 2 || PMI == 4, "row groups per wave tile");
+        constexpr int younger = decltype(younger_tag)::value;
+        if constexpr (PMI == 4)
+            asm volatile("s_waitcnt vmcnt(%12)"
+                         : "+v"(nav[0][0]), "+v"(nav[0][1]), "+v"(nav[1][0]), "+v"(nav[1][1]), "+v"(nav[2][0]), "+v"(nav[2][1]),
+                           "+v"(nav[3][0]), "+v"(nav[3][1]), "+v"(nmb[0]), "+v"(nmb[1]), "+v"(nmb[2]), "+v"(nmb[3])
+                         : "n"(younger)
+                         : "memory");
+        else if constexpr (PMI == 2)
+            asm volatile("s_waitcnt vmcnt(%6)"
+                         : "+v"(nav[0][0]), "+v"(nav[0][1]), "+v"(nav[1][0]), "+v"(nav[1][1]), "+v"(nmb[0]), "+v"(nmb[1])
+                         : "n"(younger)
+                         : "memory");
+#pragma unroll
+        for (int e = 0; e < PMI; ++e) {
+            cav[e][0] = nav[e][0];
+            cav[e][1] = nav[e][1];
+            cmb[e] = nmb[e];
         }
     };
 
@@ -367,9 +449,14 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
     const bool bias_in_lds = has_bias && p.N <= DMA_MAX_BIAS;      // wider layers read their 16 values per tile from memory
     if (bias_in_lds) stage_bias();
     setup_issue_tile();
+    const int first_m0 = i_m0, first_n0 = i_n0;
     bool issuing = true;
 #pragma unroll
     for (int i = 0; i < R - 1; ++i) issuing = issue_next() && issuing;
+    if constexpr (PF) {               // (first tile: its epilogue operands behind its first stage, waited for at once)
+        issue_epilogue_loads(first_m0, first_n0, true);
+        take_epilogue_loads(std::integral_constant<int, 0>{});
+    }
     int buf = 0;
     int v = blockIdx.x;
     while (true) {
@@ -384,21 +471,40 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
 #pragma unroll
             for (int i = 0; i < MI; ++i) acc[i][j] = b0;
         }
-        for (int ks = 0; ks < nk; ++ks) {
+        const int vn = v + gridDim.x;
+        const bool more = vn < nwg;
+        // one K step: wait for its stage, refill the stage after it, multiply
+        auto k_step = [&](bool last, bool first) {
             // This wave's share of the stage has landed: all but the (R-2)*G youngest operations are done, and
             // the operations issued after this step's group are at least the R-2 groups behind it (epilogue loads
             // and stores in between only make the wait more conservative).  Once the cursor has run out, fewer
             // groups follow: drain.
-            if (issuing) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * G) : "memory");
+            // (PF, a tile's first step: its stage was requested BEFORE the epilogue operands that the wait at the end of
+            // the previous tile -- or of the prologue -- has seen land, so it has landed too; waiting here would only
+            // wait for the previous tile's result stores, and exposing their round trip once per tile is what held the
+            // store-heavy launches at 4.2 TB/s.)
+            if (PF && first) {
+            } else if (issuing) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * G) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // ... and so has every other wave's; all waves are also done reading the stage refilled next
             __builtin_amdgcn_s_barrier();
+            // (PF: the cursor stands on the next tile's first step during this tile's last one (R == 2): that tile's
+            // epilogue operands go out behind its first operand slices)
+            const int pm0 = i_m0, pn0 = i_n0;
             if (issuing) issuing = issue_next();
+            if (PF && last) issue_epilogue_loads(pm0, pn0, more);
             if (!DIAG(4)) compute(buf);
             buf = buf + 1 == R ? 0 : buf + 1;
+        };
+        if constexpr (PF) {
+            // the last step stands outside the loop: the requests it issues define the second register set on a straight
+            // path to the wait that ends the tile (a definition under a condition or inside the loop would let the compiler
+            // place register copies of that set between the request and the wait)
+            for (int ks = 0; ks < nk - 1; ++ks) k_step(false, ks == 0);
+            k_step(true, nk == 1);
+        } else {
+            for (int ks = 0; ks < nk; ++ks) k_step(false, false);
         }
-        const int vn = v + gridDim.x;
-        const bool more = vn < nwg;
 
         // ---- epilogue, straight from the accumulators ------------------------------------------------------
         const int nb = n0 + wn * WTN + fq * 16;                       // first of this lane's 16 channels
@@ -419,20 +525,33 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
         // count is what this path is about.
         constexpr int EG = (BSTAT && MI > 2) ? 2 : MI;
         const bool has_addend = p.addend != nullptr && !DIAG(16), has_mask = p.mask_bits != nullptr && !DIAG(16);
-        if constexpr (!GEN) {
+        if (DIAG(32)) {
+            // (ablation: no epilogue at all; the accumulators are kept alive)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(acc[i][j]));
+        } else if constexpr (!GEN) {
             const int row0 = m0 + wm * WTM;                                  // wave-uniform
             const size_t e0 = (size_t)row0 * (size_t)p.N + (size_t)(n0 + wn * WTN);
-            // the descriptors end with the tensor: loads of rows past M return zeros, their stores are dropped
+            // One descriptor per tensor and row group, based at the group's first row and ending with the tensor (at most
+            // ``rows`` rows on): loads of rows past M return zeros, their stores are dropped.  The group's offset must be
+            // part of the BASE: the range check sees the vector offset and the instruction offset only, never the
+            // scalar one.
             const int rows_left = p.M - row0;
             const bool partial = rows_left < WTM;
-            const unsigned span = rows_left <= 0 ? 0u : (unsigned)((partial ? rows_left : WTM) * p.N * 2);
             const int row16 = 16 * p.N * 2;
-            const __amdgpu_buffer_rsrc_t o_rs = make_rsrc(p.out + e0, span);
-            const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(has_addend ? p.addend + e0 : nullptr, has_addend ? span : 0u);
-            const __amdgpu_buffer_rsrc_t y_rs = make_rsrc(BSTAT ? p.bstat_y + e0 : nullptr, BSTAT ? span : 0u);
-            const __amdgpu_buffer_rsrc_t m_rs = make_rsrc(has_mask ? p.mask_bits + (e0 >> 3) : nullptr, has_mask ? span >> 4 : 0u);
+            auto rows_bytes = [&](int first, int rows) -> unsigned {
+                int have = rows_left - first;
+                have = have < 0 ? 0 : (have > rows ? rows : have);
+                return (unsigned)(have * p.N * 2);
+            };
             const bool relu = FOLD && !BSTAT && p.relu_out, want_bits = FOLD && !BSTAT && p.bits_out != nullptr;
-            const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(want_bits ? p.bits_out + (e0 >> 3) : nullptr, want_bits ? span >> 4 : 0u);
+            const unsigned char* out_b = reinterpret_cast<const unsigned char*>(p.out + e0);
+            const unsigned char* add_b = reinterpret_cast<const unsigned char*>(p.addend + e0);
+            const unsigned char* y_b = reinterpret_cast<const unsigned char*>(p.bstat_y + e0);
+            const unsigned char* msk_b = p.mask_bits + (e0 >> 3);
+            const unsigned char* bit_b = p.bits_out + (e0 >> 3);
 #pragma unroll
             for (int i0 = 0; i0 < MI; i0 += EG) {
                 u32x4 yv[BSTAT ? EG : 1][2], av[EG][2];
@@ -440,15 +559,27 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
 #pragma unroll
                 for (int e = 0; e < EG; ++e) {
                     const int so = (i0 + e) * row16;
+                    if constexpr (PF) {
+                        av[e][0] = cav[PF ? i0 + e : 0][0];
+                        av[e][1] = cav[PF ? i0 + e : 0][1];
+                        mb[e] = cmb[PF ? i0 + e : 0];
+                        continue;
+                    }
+                    const unsigned nrec = rows_bytes((i0 + e) * 16, 16);
                     if (BSTAT) {
-                        yv[e][0] = __builtin_amdgcn_raw_buffer_load_b128(y_rs, (int)ep_ld, so, 0);
-                        yv[e][1] = __builtin_amdgcn_raw_buffer_load_b128(y_rs, (int)ep_ld + 16, so, 0);
+                        const __amdgpu_buffer_rsrc_t y_rs = make_rsrc(y_b + so, nrec);
+                        yv[e][0] = __builtin_amdgcn_raw_buffer_load_b128(y_rs, (int)ep_ld, 0, 0);
+                        yv[e][1] = __builtin_amdgcn_raw_buffer_load_b128(y_rs, (int)ep_ld + 16, 0, 0);
                     }
                     if (has_addend) {                                       // (non-temporal: last use of the tensor)
-                        av[e][0] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)ep_ld, so, 2);
-                        av[e][1] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)ep_ld + 16, so, 2);
+                        const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(add_b + so, nrec);
+                        av[e][0] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)ep_ld, 0, 2);
+                        av[e][1] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)ep_ld + 16, 0, 2);
                     }
-                    if (has_mask) mb[e] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(m_rs, (int)(ep_ld >> 4), so >> 4, 0);
+                    if (has_mask) {
+                        const __amdgpu_buffer_rsrc_t m_rs = make_rsrc(msk_b + (so >> 4), nrec >> 4);
+                        mb[e] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(m_rs, (int)(ep_ld >> 4), 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int e = 0; e < EG; ++e) {
@@ -485,7 +616,9 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
 #pragma unroll
                         for (int d = 0; d < 8; ++d) pk[d] = pk_relu(pk[d]);
                     }
-                    if (want_bits) {
+                    // (PF: issued whether or not the mask is wanted -- an absent tensor has a descriptor of zero records --
+                    // so that the number of stores behind the next tile's requests is a constant)
+                    if (want_bits || (PF && FOLD)) {
                         // after the clamp a half is 0x0000 .. 0x7fff (or a NaN pattern >= 0x7f81): adding 0x7fff sets bit 15
                         // of exactly the positive ones, with no carry into the upper half
                         unsigned m16 = 0;
@@ -502,12 +635,13 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
                                 m16 &= ~(neg << (2 * d));
                             }
                         }
-                        __builtin_amdgcn_raw_buffer_store_b16((short)m16, b_rs, (int)(ep_ld >> 4), so >> 4, 0);
+                        const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(bit_b + (so >> 4), want_bits ? rows_bytes(i * 16, 16) >> 4 : 0u);
+                        __builtin_amdgcn_raw_buffer_store_b16((short)m16, b_rs, (int)(ep_ld >> 4), 0, 0);
                     }
                     auto add_stats = [&]() {
                         // rows past M (last tile only) were computed from a repeated input row: keep them out of the sums
                         if (partial && (BSTAT || want_stats) && i * 16 + frow >= rows_left) return;
-                        if (BSTAT) {
+                        if constexpr (BSTAT) {
 #pragma unroll
                             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -525,14 +659,23 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
                                     s0[k + 1] += d1;
                                     s1[k + 1] += d1 * (y1 - ctr[k + 1]);
                                 }
+                        } else if constexpr (NOSTATS) {
                         } else if (want_stats) {
+                            if constexpr (PF) {
 #pragma unroll
-                            for (int d = 0; d < 8; ++d) {
-                                const float a = bf_lo(pk[d]) - ctr[2 * d], b = bf_hi(pk[d]) - ctr[2 * d + 1];
-                                s0[2 * d] += a;
-                                s1[2 * d] += a * a;
-                                s0[2 * d + 1] += b;
-                                s1[2 * d + 1] += b * b;
+                                for (int d = 0; d < 8; ++d) {
+                                    s0[2 * d] += bf_lo(pk[d]);
+                                    s0[2 * d + 1] += bf_hi(pk[d]);
+                                }
+                            } else {
+#pragma unroll
+                                for (int d = 0; d < 8; ++d) {
+                                    const float a = bf_lo(pk[d]) - ctr[PF ? 0 : 2 * d], b = bf_hi(pk[d]) - ctr[PF ? 0 : 2 * d + 1];
+                                    s0[2 * d] += a;
+                                    s1[PF ? 0 : 2 * d] += a * a;
+                                    s0[2 * d + 1] += b;
+                                    s1[PF ? 0 : 2 * d + 1] += b * b;
+                                }
                             }
                         }
                     };
@@ -547,8 +690,10 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
                             second[d] = up ? pk[4 + d] : got;
                         }
                         if (!DIAG(1)) {
-                            __builtin_amdgcn_raw_buffer_store_b128(first, o_rs, (int)ep_st, so, 2);
-                            __builtin_amdgcn_raw_buffer_store_b128(second, o_rs, (int)ep_st, so + (row16 >> 1), 2);
+                            const __amdgpu_buffer_rsrc_t o1 = make_rsrc(out_b + so, rows_bytes(i * 16, 8));
+                            const __amdgpu_buffer_rsrc_t o2 = make_rsrc(out_b + so + (row16 >> 1), rows_bytes(i * 16 + 8, 8));
+                            __builtin_amdgcn_raw_buffer_store_b128(first, o1, (int)ep_st, 0, 2);
+                            __builtin_amdgcn_raw_buffer_store_b128(second, o2, (int)ep_st, 0, 2);
                         }
                     };
                     if (BSTAT) {
@@ -718,20 +863,26 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
         }
         }
         }
+        // (PF: the lean epilogue issued two result stores per row group, three with the sign mask, behind the requests)
+#ifdef PDT_DMA_DIAG
+        if constexpr (PF) take_epilogue_loads(std::integral_constant<int, 0>{});      // (the ablation build may skip stores)
+#else
+        if constexpr (PF) take_epilogue_loads(std::integral_constant<int, (FOLD ? 3 : 2) * MI>{});
+#endif
         if (!more) break;
         v = vn;
     }
     if (want_stats && stat_n0 >= 0) flush_stats(stat_n0);
 }
 
-template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD, bool GEN>
+template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD, bool GEN, bool PF>
 static int g1_resident_blocks_of() {
     static int cached = 0;
     if (cached > 0) return cached;
     int per_cu = 0, dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 512;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_dma_kernel<BN, WM, WN, BK, R, BSTAT, FOLD, GEN>, 256, 0) != hipSuccess || per_cu <= 0)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_dma_kernel<BN, WM, WN, BK, R, BSTAT, FOLD, GEN, PF>, 256, 0) != hipSuccess || per_cu <= 0)
         per_cu = 2;
     cached = per_cu * cus;
     return cached;
@@ -739,28 +890,36 @@ static int g1_resident_blocks_of() {
 
 template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD = false>
 static int g1_resident_blocks() {
-    return g1_resident_blocks_of<BN, WM, WN, BK, R, BSTAT, FOLD, false>();
+    return g1_resident_blocks_of<BN, WM, WN, BK, R, BSTAT, FOLD, false, false>();
 }
 
-template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD, bool GEN>
+template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD, bool GEN, bool PF>
 static int g1_launch_of(const ConvDmaParams& p, hipStream_t s) {
     long long nwg = (long long)((p.M + 127) / 128) * (p.N / BN);
     if (nwg <= 0 || nwg > 0x7fffffffLL) return -2;
-    long long grid = g1_resident_blocks_of<BN, WM, WN, BK, R, BSTAT, FOLD, GEN>();
+    long long grid = g1_resident_blocks_of<BN, WM, WN, BK, R, BSTAT, FOLD, GEN, PF>();
     if (grid > nwg) grid = nwg;
     if (g_pdt_deterministic && grid > p.nrep) grid = p.nrep;      // one statistics row per workgroup
-    hipLaunchKernelGGL((conv_dma_kernel<BN, WM, WN, BK, R, BSTAT, FOLD, GEN>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_dma_kernel<BN, WM, WN, BK, R, BSTAT, FOLD, GEN, PF>), dim3((unsigned)grid), dim3(256), 0, s, p);
     return pdt_launch_status();
 }
+
+// PDT_DMA_PREFETCH=0: never pick the prefetching instantiations (A/B measurements)
+static const bool g_dma_prefetch = !(getenv("PDT_DMA_PREFETCH") && atoi(getenv("PDT_DMA_PREFETCH")) == 0);
 
 template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD = false>
 static int g1_launch(const ConvDmaParams& p, hipStream_t s) {
     // the lean epilogue wants output row == GEMM row and a full-resolution addend (always true with a second operand /
     // start values: the launcher admits only the plain 1x1 geometry there)
-    if (!FOLD && (!p.simple_out || p.addend_half)) {
-        if constexpr (!FOLD) return g1_launch_of<BN, WM, WN, BK, R, BSTAT, false, true>(p, s);
+    if constexpr (!FOLD) {
+        if (!p.simple_out || p.addend_half) return g1_launch_of<BN, WM, WN, BK, R, BSTAT, false, true, false>(p, s);
     }
-    return g1_launch_of<BN, WM, WN, BK, R, BSTAT, FOLD, false>(p, s);
+    if constexpr (!BSTAT && R == 2) {
+        // epilogue operands to hide, and statistics (if any) that are plain sums
+        if (g_dma_prefetch && (p.addend || p.mask_bits) && (!p.stat_acc || p.sums_only))
+            return g1_launch_of<BN, WM, WN, BK, R, false, FOLD, false, true>(p, s);
+    }
+    return g1_launch_of<BN, WM, WN, BK, R, BSTAT, FOLD, false, false>(p, s);
 }
 
 // tile: 0 = auto (3 when N is a multiple of 128, else 4); 3 = 128 x 128 with K slices of 64 and two stages, 4 = 128 x 64
@@ -785,7 +944,7 @@ PDT_API int pdt_conv_dma_ex(const void* in, const void* wgt, void* out, const vo
                             int Wi, int pix_stride, int Ci, int Hg, int Wg, int IS, int Ho, int Wo, int OS, int oy0, int ox0,
                             int N, int wrow, int T, const signed char* offy, const signed char* offx,
                             const unsigned short* widx, int tile, const void* in2, int Ci2, int pix_stride2,
-                            const float* bias, int relu_out, void* bits_out, hipStream_t s) {
+                            const float* bias, int relu_out, void* bits_out, int sums_only, hipStream_t s) {
     if (T <= 0 || T > DMA_MAX_TAPS) return -3;
     if (M <= 0) return 0;
     if (!in2) Ci2 = 0;
@@ -799,6 +958,7 @@ PDT_API int pdt_conv_dma_ex(const void* in, const void* wgt, void* out, const vo
         if (M * (long long)pix_stride2 * 2 >= 0x7fff0000LL) return -7;
     }
     if ((relu_out || bits_out) && (!(in2 || bias) || bstat_y)) return -12;   // forward instantiations with a second operand / start values only
+    if ((in2 || bias) && stat_acc && !bstat_y) return -12;                   // ... which carry no statistics epilogue
     if (tile == 5) {
         // K slices of 32 over a gathered operand whose "pixels" may overlap (the stem reads 32 consecutive values of its
         // packed NHWC4 image per tap: pix_stride 4, Ci 32): every DMA source address must still be 16-byte aligned
@@ -826,6 +986,7 @@ PDT_API int pdt_conv_dma_ex(const void* in, const void* wgt, void* out, const vo
     p.nrep = pdt_nrep();
     p.in2 = (const bf16*)in2; p.bias = bias; p.Ci2 = Ci2; p.pix_stride2 = in2 ? pix_stride2 : 0;
     p.relu_out = relu_out ? 1 : 0; p.bits_out = (unsigned char*)bits_out;
+    p.sums_only = (sums_only && stat_acc && !stat_shift && !bstat_y) ? 1 : 0;
 #ifdef PDT_DMA_DIAG
     { const char* e = getenv("PDT_DMA_DIAG"); p.diag = e ? atoi(e) : 0; }
 #endif
@@ -866,8 +1027,8 @@ PDT_API int pdt_conv_dma(const void* in, const void* wgt, void* out, const void*
                          const float* bstat_mean, const float* bstat_scale, const float* bstat_shift, long long M, int Hi,
                          int Wi, int pix_stride, int Ci, int Hg, int Wg, int IS, int Ho, int Wo, int OS, int oy0, int ox0,
                          int N, int wrow, int T, const signed char* offy, const signed char* offx,
-                         const unsigned short* widx, int tile, hipStream_t s) {
+                         const unsigned short* widx, int tile, int sums_only, hipStream_t s) {
     return pdt_conv_dma_ex(in, wgt, out, addend, addend_half, mask_bits, stat_acc, stat_shift, bstat_y, bstat_mean,
                            bstat_scale, bstat_shift, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, wrow,
-                           T, offy, offx, widx, tile, nullptr, 0, 0, nullptr, 0, nullptr, s);
+                           T, offy, offx, widx, tile, nullptr, 0, 0, nullptr, 0, nullptr, sums_only, s);
 }

@@ -80,12 +80,12 @@ _sig("pdt_conv_igemm", _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _ll, _i, 
 _sig("pdt_conv_igemm_bstats", _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i,
      _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp)
 _sig("pdt_conv_dma", _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-     _i, _i, _i, _vp, _vp, _vp, _i, _vp)
+     _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp)
 _sig("pdt_conv_wgrad", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _ll, _vp)
 _sig("pdt_conv_wgrad_ex", _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _ll,
      _vp, _vp)
 _sig("pdt_conv_dma_ex", _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-     _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp)
+     _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp)
 _sig("pdt_bnfold_fwd_stats", _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp)
 _sig("pdt_bnfold_scale_weights", _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp)
 _sig("pdt_bnfold_prepare", _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp)
@@ -315,7 +315,7 @@ def _part(t, b0: int, b1: int):
 
 def _igemm(inp, wgt, out, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, ldo, wrow, taps: _Taps,
            addend=None, mask=None, bias=None, stat_acc=None, stat_shift=None, tile: int = 0, bstat=None,
-           mask_bits: bool = False, addend_half: bool = False) -> None:
+           mask_bits: bool = False, addend_half: bool = False, sums_only: bool = False) -> None:
     parts = _batch_parts(inp.shape[0], inp.numel() * inp.element_size())
     if parts is not None:
         B = inp.shape[0]
@@ -326,7 +326,7 @@ def _igemm(inp, wgt, out, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0
             _igemm(inp[b0:b1], wgt, out[b0:b1], (M // B) * (b1 - b0), Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS,
                    oy0, ox0, N, ldo, wrow, taps, addend=_part(addend, b0, b1), mask=_part(mask, b0, b1), bias=bias,
                    stat_acc=stat_acc, stat_shift=stat_shift, tile=tile, bstat=sub, mask_bits=mask_bits,
-                   addend_half=addend_half)
+                   addend_half=addend_half, sums_only=sums_only)
         return
     if (_USE_CONV_DMA and tile <= 0 and bias is None and ldo == N and N % 64 == 0 and Ci % 64 == 0 and taps.T >= 1
             and pix_stride % 8 == 0 and (mask is None or mask_bits) and (_DMA_TAPS or taps.T == 1)
@@ -334,7 +334,8 @@ def _igemm(inp, wgt, out, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0
         acc, by, bmean, bscale, bshift = bstat if bstat is not None else (stat_acc, None, None, None, None)
         rc = _lib.pdt_conv_dma(_p(inp), _p(wgt), _p(out), _p(addend), int(addend_half), _p(mask), _p(acc), _p(stat_shift),
                                _p(by), _p(bmean), _p(bscale), _p(bshift), M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS,
-                               oy0, ox0, N, wrow, taps.T, taps.offy, taps.offx, taps.widx, -tile or _DMA_TILE, _stream())
+                               oy0, ox0, N, wrow, taps.T, taps.offy, taps.offx, taps.widx, -tile or _DMA_TILE, int(sums_only),
+                               _stream())
         _check(rc, "pdt_conv_dma")
         return
     tile = max(tile, 0)
@@ -521,7 +522,7 @@ def stem_fprop(x0: torch.Tensor, wp: torch.Tensor, stat_shift: Optional[torch.Te
         # the LDS-DMA kernel with K slices of 32 (one tap = one slice of the packed image)
         rc = _lib.pdt_conv_dma(_p(x0), _p(wp), _p(y), None, 0, None, _p(acc), _p(stat_shift), None, None, None, None, M,
                                Hp, Wp, 4, 32, Ho, Wo, 2, Ho, Wo, 1, 0, 0, Co, 7 * 32, taps.T, taps.offy, taps.offx,
-                               taps.widx, 5, _stream())
+                               taps.widx, 5, 0, _stream())
         _check(rc, "pdt_conv_dma (stem)")
     else:
         _igemm(x0, wp, y, M, Hp, Wp, 4, 32, Ho, Wo, 2, Ho, Wo, 1, 0, 0, Co, Co, 7 * 32, taps,
@@ -638,7 +639,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
     if stride == 1:
         _igemm(dy, wt, dx, B * Hi * Wi, Ho, Wo, Co, Co, Hi, Wi, 1, Hi, Wi, 1, 0, 0, Ci, Ci, R * S * Co,
                _dgrad_taps(R, S, pad, 1, 0, 0), addend=addend, mask=mask_src, tile=tile, bstat=bstat, mask_bits=bits,
-               addend_half=addend_half, stat_acc=gacc)
+               addend_half=addend_half, stat_acc=gacc, sums_only=gacc is not None)
         return dx
     for ph in range(stride):
         for pw in range(stride):
@@ -648,16 +649,16 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
                 continue
             _igemm(dy, wt, dx, B * Hg * Wg, Ho, Wo, Co, Co, Hg, Wg, 1, Hi, Wi, stride, ph, pw, Ci, Ci, R * S * Co,
                    _dgrad_taps(R, S, pad, stride, ph, pw), addend=addend, mask=mask_src, tile=tile, bstat=bstat,
-                   mask_bits=bits, addend_half=addend_half, stat_acc=gacc)
+                   mask_bits=bits, addend_half=addend_half, stat_acc=gacc, sums_only=gacc is not None)
     return dx
 
 
 def grad_sums(C: int, device: torch.device) -> torch.Tensor:
-    """``[2, C]``: per-channel sum and sum of squares of the last gradient produced with
-    ``conv_dgrad(out_sums=True)`` (collects and re-zeroes the accumulator)."""
+    """``[C]``: per-channel sums of the last gradient produced with ``conv_dgrad(out_sums=True)`` (collects and
+    re-zeroes the accumulator)."""
     out = torch.empty(2, C, dtype=torch.float32, device=device)
     _check(_lib.pdt_bn_moments(_p(_accumulator(device, C, "gsum")), _p(out), C, 1.0, _stream()), "pdt_bn_moments")
-    return out
+    return out[0]
 
 
 def colsum_take(slot: str, C: int, device: torch.device) -> torch.Tensor:
@@ -981,7 +982,7 @@ def conv_dgrad_folded(g: torch.Tensor, a_in: torch.Tensor, fold: BnFold, bwd_sta
         rc = _lib.pdt_conv_dma_ex(_p(g[b0:b1]), _p(fold.wfold), _p(dx[b0:b1]), None, 0, None, _p(acc), None,
                                   _p(by[b0:b1]) if by is not None else None, _p(bmean), _p(bscale), _p(bshift), M, H, W, N,
                                   N, H, W, 1, H, W, 1, 0, 0, C, N + C, 1, taps.offy, taps.offx, taps.widx, tile,
-                                  _p(a_in[b0:b1]), C, C, _p(fold.bias), 0, None, _stream())
+                                  _p(a_in[b0:b1]), C, C, _p(fold.bias), 0, None, 0, _stream())
         _check(rc, "pdt_conv_dma_ex")
     return dx
 
@@ -1075,7 +1076,7 @@ def conv_fprop_fused_tail(a: torch.Tensor, wf: torch.Tensor, shift: torch.Tensor
         rc = _lib.pdt_conv_dma_ex(_p(a[b0:b1]), _p(wf), _p(y[b0:b1]), _p(_part(addend, b0, b1)), 0, None, None, None, None,
                                   None, None, None, M, H, W, C, C, H, W, 1, H, W, 1, 0, 0, N, C + C2, 1, taps.offy,
                                   taps.offx, taps.widx, tile, _p(_part(in2, b0, b1)), C2, C2, _p(shift), 1,
-                                  _p(_part(bits_out, b0, b1)), _stream())
+                                  _p(_part(bits_out, b0, b1)), 0, _stream())
         _check(rc, "pdt_conv_dma_ex")
     return y
 

@@ -136,9 +136,8 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: Optional[torch.Tensor], in
         dx = dx * _unpack_bits(relu_bits)
     elif relu_mask is not None:
         dx = dx * (relu_mask > 0)
-    if out_sums:         # per-channel sum / sum of squares of the stored result, collected by grad_sums
-        d2 = dx.float().reshape(-1, Ci)
-        _grad_sums[Ci] = torch.stack([d2.sum(0), (d2 * d2).sum(0)])
+    if out_sums:         # per-channel sums of the stored result, collected by grad_sums
+        _grad_sums[Ci] = dx.float().reshape(-1, Ci).sum(0)
     return dx
 
 
@@ -146,7 +145,7 @@ _grad_sums = {}
 
 
 def grad_sums(C: int, device=None) -> torch.Tensor:
-    """``[2, C]`` sums left by the last ``conv_dgrad(out_sums=True)`` with ``C`` output channels."""
+    """``[C]`` sums left by the last ``conv_dgrad(out_sums=True)`` with ``C`` output channels."""
     return _grad_sums.pop(C)
 
 

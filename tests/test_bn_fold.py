@@ -75,7 +75,7 @@ def test_backward_sums_from_the_weight_gradient_product():
     wt = None
     d = ref.conv_dgrad(g, w, wt, tuple(a.shape), 1, 1, 1, 0, out_sums=True)
     gs = ref.grad_sums(16)
-    assert torch.allclose(gs[0], d.reshape(-1, 16).sum(0), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(gs, d.reshape(-1, 16).sum(0), rtol=1e-5, atol=1e-5)
 
 
 def test_engine_with_and_without_the_folded_path(monkeypatch):
@@ -317,8 +317,7 @@ def test_hip_dgrad_leaves_the_sums_of_its_result(hip, device):
     dx = hip.conv_dgrad(dy, w, wt, (B, H, H, Ci), 1, 1, 1, 0, addend=addend, relu_bits=bits, out_sums=True)
     gs = hip.grad_sums(Ci, device)
     d2 = dx.float().reshape(-1, Ci)
-    assert torch.allclose(gs[0], d2.sum(0), rtol=1e-3, atol=1e-3 * d2.sum(0).abs().max().item())
-    assert torch.allclose(gs[1], (d2 * d2).sum(0), rtol=1e-3, atol=1e-3)
+    assert torch.allclose(gs, d2.sum(0), rtol=1e-3, atol=1e-3 * d2.sum(0).abs().max().item())
     assert rel_err(dx, ref.conv_dgrad(dy, w, None, (B, H, H, Ci), 1, 1, 1, 0, addend=addend, relu_bits=bits)) < 1.5e-2
     assert hip.grad_sums(Ci, device).abs().max().item() == 0.0           # collected: the accumulator is clean again
 

@@ -175,3 +175,60 @@ def test_wgrad_split_k_depths(hip, device, cfg):
     hip.conv_wgrad(x[: B // 2], dy[: B // 2], k, k, stride, pad, dw2, tile=tile, target_blocks=1024)
     hip.conv_wgrad(x[B // 2:], dy[B // 2:], k, k, stride, pad, dw2, tile=tile, target_blocks=64)
     assert rel_l2(dw2, dw_ref) < 2e-3
+
+
+def _guarded(shape, dtype, device, fill):
+    """A tensor of ``shape`` in the middle of a larger allocation filled with ``fill``: (tensor, check) where check()
+    says whether the bands in front of and behind it are untouched."""
+    n = 1
+    for s in shape:
+        n *= s
+    pad = 64 * 1024
+    whole = torch.full((n + 2 * pad,), fill, dtype=dtype, device=device)
+    t = whole[pad:pad + n].view(*shape)
+
+    def untouched() -> bool:
+        return bool((whole[:pad] == fill).all()) and bool((whole[pad + n:] == fill).all())
+
+    return t, untouched
+
+
+@pytest.mark.parametrize("B,H,C,N", [(3, 7, 64, 256), (5, 9, 128, 64), (1, 5, 64, 128), (13, 7, 256, 1024), (2, 10, 64, 64)])
+def test_epilogue_stays_inside_its_tensors(hip, device, B, H, C, N):
+    """Row counts that are no multiple of the 128-row tile (the last tile is partial, some wave tiles are empty): results
+    and sign masks are written through buffer descriptors whose range check must end every tensor exactly -- the bytes
+    around the outputs stay untouched, and the partial tile's rows are right."""
+    torch.manual_seed(B * 100 + H)
+    a = rnd(B, H, H, C, device=device)
+    x = rnd(B, H, H, N, device=device)
+    w = rnd(N, 1, 1, C, device=device, scale=0.1)
+    shift = torch.randn(N, device=device) * 0.1
+    # forward with fused statistics
+    y, ok_y = _guarded((B, H, H, N), torch.bfloat16, device, 7.0)
+    _, mom = hip.conv_fprop(a, w, 1, 1, 1, 0, stat_shift=shift, out=y)
+    y_ref, mom_ref = ref.conv_fprop(a, w, 1, 1, 1, 0, stat_shift=shift)
+    assert ok_y() and rel_l2(y, y_ref) < 1e-2
+    assert torch.allclose(hip.stats_to_moments(mom), mom_ref, rtol=2e-2, atol=2e-2)
+    # fused block tail: addend, ReLU, packed sign mask
+    wf = w.view(N, C).contiguous()
+    out, ok_o = _guarded((B, H, H, N), torch.bfloat16, device, 7.0)
+    bits, ok_b = _guarded((B, H, H, N // 8), torch.uint8, device, 0x5a)
+    hip.conv_fprop_fused_tail(a, wf, shift, addend=x, bits_out=bits, out=out)
+    want_bits = torch.zeros(B, H, H, N // 8, dtype=torch.uint8, device=device)
+    out_ref = ref.conv_fprop_fused_tail(a, wf, shift, addend=x, bits_out=want_bits)
+    assert ok_o() and ok_b() and rel_l2(out, out_ref) < 1e-2
+    assert torch.equal(ref._unpack_bits(bits), out > 0)
+    # block-entry data gradient: addend, packed mask, per-channel sums of the result
+    dy = rnd(B, H, H, N, device=device)
+    wt = torch.empty(C, 1, 1, N, dtype=torch.bfloat16, device=device)
+    hip.transpose_weights(w, wt)
+    res = rnd(B, H, H, C, device=device)
+    mbits = hip.new_relu_bits(res)
+    mbits.copy_(torch.randint(0, 256, tuple(mbits.shape), device=device, dtype=torch.uint8))
+    dx, ok_d = _guarded((B, H, H, C), torch.bfloat16, device, 7.0)
+    hip.conv_dgrad(dy, w, wt, (B, H, H, C), 1, 1, 1, 0, addend=res, relu_bits=mbits, out=dx, out_sums=True)
+    sums = hip.grad_sums(C, device)
+    dx_ref = ref.conv_dgrad(dy, w, None, (B, H, H, C), 1, 1, 1, 0, addend=res, relu_bits=mbits)
+    assert ok_d() and rel_l2(dx, dx_ref) < 1.5e-2
+    want = dx.float().reshape(-1, C).sum(0)
+    assert torch.allclose(sums, want, rtol=1e-3, atol=1e-3 * want.abs().max().item() + 1e-3)
