@@ -18,15 +18,30 @@ overlapped on a side stream, fused SGD step.  Weak scaling: the per-GPU batch is
 Three set-up steps in which the engine records its step program (``--setup-steps``, reported in the JSON line),
 W un-timed warm-up steps, then exactly K timed steps bracketed by barrier +
 ``torch.cuda.synchronize()``; the time is the MAX over ranks; rank 0 prints one JSON line.
+
+``--cfg-filepath config/ResNet50.yml`` (or ``config/test-sync.yml``, ...) takes model, optimizer, SyncBN switch, bucket
+size and the batch from a trainer config the way the trainer reads it (the YAML's ``batch_size`` is per NODE and is
+divided by the number of GPUs, reference ``train_distributed.py:191-195``; ``per_gpu_batch_size`` wins when present);
+the dataset is replaced by synthetic data of the same shape.  Command-line values given explicitly override the file.
+
+With more than one rank (or forced one-rank collectives) the communication library's own start-up log is captured
+(``NCCL_DEBUG=INFO``, subsystems INIT/GRAPH/ENV: no per-call output inside the timed region) and rank 0 reports what RCCL
+chose -- ranks, channels, rings, transports -- under ``config.rccl``; ``--rccl-tuning-log 1`` adds the per-collective
+algorithm / protocol choices (it logs every call, so it is off by default).  A run whose step recording failed
+(``step_replay: eager(failed)``) still prints its line and then exits with status 4: an eager step costs several times the
+host time and must not pass for the real thing.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -119,6 +134,86 @@ def self_launch(n_ranks: int, argv, timeout_s: float = 3000.0, script: str = Non
     return 0
 
 
+def rccl_log_setup(tuning: bool) -> str:
+    """Point the communication library's debug log of THIS process at a file of its own (before the process group
+    exists: the variables are read when the communicator is created).  Returns the file's path."""
+    base = os.environ.get("PDT_RCCL_LOG_DIR") or tempfile.mkdtemp(prefix="pdt_rccl_")
+    os.makedirs(base, exist_ok=True)
+    path = os.path.join(base, f"rccl_rank{os.environ.get('RANK', '0')}.log")
+    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,ENV" + (",TUNING" if tuning else ""))
+    os.environ["NCCL_DEBUG_FILE"] = path
+    return path
+
+
+def parse_rccl_log(text: str) -> dict:
+    """What the library said it set up: enough to tell a ring over one xGMI link from a multi-channel mesh without
+    opening the log.  Every field is best effort (the wording differs between releases); ``lines`` is the size of the
+    log, ``excerpt`` its first matching lines verbatim."""
+    out: dict = {"lines": text.count("\n")}
+    m = re.search(r"(?:RCCL|NCCL) version ([^\s]+)", text)
+    if m:
+        out["version"] = m.group(1)
+    m = re.search(r"nranks (\d+)", text)
+    if m:
+        out["nranks"] = int(m.group(1))
+    m = re.search(r"(\d+) coll channels, (\d+) (?:collnet|nvls) channels.*?(\d+) p2p channels(?:, (\d+) p2p channels per peer)?", text)
+    if m:
+        out["coll_channels"], out["p2p_channels"] = int(m.group(1)), int(m.group(3))
+        if m.group(4):
+            out["p2p_channels_per_peer"] = int(m.group(4))
+    rings = re.findall(r"(?m)Channel (\d+)/(\d+) :((?: +\d+)+) *$", text)
+    if rings:
+        out["channels"] = int(rings[0][1])
+        out["rings"] = sorted({" ".join(r[2].split()) for r in rings})[:8]
+    trees = re.findall(r"Trees ((?:\[\d+\] [-\d/>]+ ?)+)", text)
+    if trees:
+        out["trees"] = trees[0].strip()[:200]
+    transports = sorted(set(re.findall(r"via ([A-Za-z0-9/_]+(?:/[A-Za-z0-9_]+)*)", text)))
+    if transports:
+        out["transports"] = transports[:8]
+    env = sorted(set(re.findall(r"(NCCL_[A-Z0-9_]+|RCCL_[A-Z0-9_]+) set by environment to ([^\s.]+)", text)))
+    if env:
+        out["env"] = {k: v for k, v in env if k != "NCCL_DEBUG_FILE"}
+    tuning = re.findall(r"(AllReduce|Broadcast|AllGather|ReduceScatter): (\d+) Bytes -> Algo (\d+) proto (\d+)", text)
+    if tuning:
+        algo = {"0": "tree", "1": "ring", "2": "collnet_direct", "3": "collnet_chain"}
+        proto = {"0": "LL", "1": "LL128", "2": "simple"}
+        seen = {}
+        for coll, nbytes, a, pr in tuning:
+            seen[(coll, int(nbytes))] = f"{algo.get(a, a)}/{proto.get(pr, pr)}"
+        out["choices"] = [{"collective": c, "bytes": b, "algo_proto": v} for (c, b), v in sorted(seen.items())][:24]
+    keep = [ln for ln in text.splitlines() if re.search(r"Channel \d+/|coll channels|Trees|via |version|nranks", ln)]
+    out["excerpt"] = [ln[-160:] for ln in keep[:6]]
+    return out
+
+
+def cfg_from_file(path: str, args, explicit: set) -> dict:
+    """Trainer YAML -> the benchmark's config: the file decides what the command line did not spell out."""
+    from pytorch_distributed_training_amd.config import get_cfg
+    cfg = get_cfg(path)
+    tr = cfg["training"]
+    gpus = max(args.gpus, 1)
+    if "batch" not in explicit:
+        args.batch = int(tr.get("per_gpu_batch_size") or max(int(tr["batch_size"]) // gpus, 1))
+    if "model" not in explicit:
+        args.model = cfg["model"]["name"]
+    if "sync_bn" not in explicit:
+        args.sync_bn = int(bool(tr.get("sync_bn", False)))
+    if "bucket_cap_mb" not in explicit:
+        args.bucket_cap_mb = float(tr.get("bucket_cap_mb", 25.0))
+    if "engine" not in explicit:
+        args.engine = tr.get("engine", "native")
+    cfg["dataset"] = {"name": "synthetic", "n_classes": int(cfg["dataset"].get("n_classes", 1000)),
+                      "image_size": args.image_size, "input_format": args.input_format}
+    tr.update({"train_iters": args.steps + args.warmup, "batch_size": args.batch * gpus, "per_gpu_batch_size": args.batch,
+               "sync_bn": bool(args.sync_bn), "precision": "bf16", "bucket_cap_mb": args.bucket_cap_mb,
+               "engine": args.engine})
+    for key in ("resume", "checkpoint_dir", "checkpoint_interval"):
+        tr.pop(key, None)
+    return validate_cfg(cfg)
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,7 +233,14 @@ def main() -> int:
     ap.add_argument("--backend", type=str, default="nccl")
     ap.add_argument("--setup-steps", type=int, default=3,
                     help="untimed steps before the warm-up in which the engine records its step (see main)")
+    ap.add_argument("--cfg-filepath", type=str, default="",
+                    help="trainer YAML (config/ResNet50.yml, config/test-sync.yml, ...): model, optimizer, SyncBN, "
+                         "bucket size and batch come from it unless given on the command line; data stays synthetic")
+    ap.add_argument("--rccl-tuning-log", type=int, default=0,
+                    help="1: also capture RCCL's per-collective algorithm / protocol choices (logs every call)")
     args = ap.parse_args()
+    explicit = {a.dest for a in ap._actions if any(o in sys.argv[1:] or any(x.startswith(o + "=") for x in sys.argv[1:])
+                                                    for o in a.option_strings)}
 
     hang_dump = float(os.environ.get("PDT_HANG_DUMP_S", "0") or 0)
     if hang_dump > 0:                 # debug aid: every thread's Python stack if the run is still going then
@@ -148,6 +250,9 @@ def main() -> int:
     if args.gpus > 1 and not dist_env.env_launch_detected():
         return self_launch(args.gpus, sys.argv[1:])          # nothing here has touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    rccl_log = None
+    if args.backend == "nccl" and (world > 1 or os.environ.get("PDT_FORCE_COLLECTIVES") == "1"):
+        rccl_log = rccl_log_setup(bool(args.rccl_tuning_log))
     if world > 1 or args.gpus > 1 or dist_env.env_launch_detected():
         if world != args.gpus:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
@@ -160,7 +265,7 @@ def main() -> int:
         print("bench.py: no GPU visible", file=sys.stderr)
         return 2
 
-    cfg = validate_cfg({
+    cfg = cfg_from_file(args.cfg_filepath, args, explicit) if args.cfg_filepath else validate_cfg({
         "dataset": {"name": "synthetic", "n_classes": 1000, "image_size": args.image_size,
                     "input_format": args.input_format},
         "training": {
@@ -174,7 +279,8 @@ def main() -> int:
     })
     torch.manual_seed(1029)
     engine = build_engine(cfg, device)
-    source = synthetic_batches(args.batch, args.image_size, 1000, args.input_format, device, args.data_mode,
+    n_classes = int(cfg["dataset"]["n_classes"])
+    source = synthetic_batches(args.batch, args.image_size, n_classes, args.input_format, device, args.data_mode,
                                seed=info.rank)
     batches = DevicePrefetcher(source, device) if args.data_mode == "h2d" else source
 
@@ -217,6 +323,16 @@ def main() -> int:
     final_loss = float(loss) if loss is not None else float("nan")
     global_batch = args.batch * info.world_size
     value = global_batch * args.steps / elapsed
+    replay_mode = engine.model.active_replay_mode() if native else None
+    rccl = None
+    if rccl_log and info.rank == 0:
+        try:
+            texts = [open(f, errors="replace").read() for f in sorted(glob.glob(rccl_log + "*"))]
+            rccl = parse_rccl_log("\n".join(texts)) if texts else {"lines": 0}
+            rccl["log"] = rccl_log
+        except OSError as exc:
+            rccl = {"error": str(exc)}
+    opt = cfg["training"]["optimizer"]
     if info.rank == 0:
         print(json.dumps({
             "metric": f"train images/sec (whole node) {args.model} bf16",
@@ -236,7 +352,9 @@ def main() -> int:
                 "setup_steps": args.setup_steps,
                 "image_size": args.image_size, "seq_len": None,
                 "parallelism": f"dp{info.world_size}" + ("+syncbn" if (args.sync_bn and info.world_size > 1) else ""),
-                "engine": args.engine, "optimizer": "SGD momentum 0.9 wd 1e-4", "final_loss": round(final_loss, 4),
+                "engine": args.engine,
+                "optimizer": f"{opt['name']} momentum {opt.get('momentum', 0)} wd {opt.get('weight_decay', 0):g}",
+                "cfg_file": args.cfg_filepath or None, "final_loss": round(final_loss, 4),
                 "peak_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
                 "rccl_world": dist.get_world_size() if dist.is_initialized() else 1,
                 "backend": dist.get_backend() if dist.is_initialized() else None,
@@ -254,13 +372,20 @@ def main() -> int:
                 "comm_healthy": bool(healthy),
                 "host_submit_ms_per_step": round(1e3 * enqueue / args.steps, 3),
                 "syncbn_comm": engine.model.syncbn_comm if (args.engine == "native" and engine.model.sync_bn) else None,
-                "step_replay": engine.model.active_replay_mode() if native else None,
+                "step_replay": replay_mode,
                 "sync_bn_active": bool(engine.model.sync_bn) if args.engine == "native" else None,
+                "rccl": rccl,
             },
         }), flush=True)
     if dist.is_initialized():
         dist_env.shutdown()
-    return 0 if healthy else 3
+    if not healthy:
+        return 3
+    if replay_mode == "eager(failed)":
+        print("bench.py: the step recording failed and the timed steps ran eagerly (see the warning above): the number is "
+              "not the engine's", file=sys.stderr)
+        return 4
+    return 0
 
 
 if __name__ == "__main__":

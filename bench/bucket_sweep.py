@@ -1,7 +1,11 @@
 """Gradient-bucket size sweep for the xGMI all-reduce overlap.
 
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port 29500 bench/bucket_sweep.py --model ResNet152 --batch 128 --caps 4,8,16,25,50,100,200
+    python bench/bucket_sweep.py --gpus N --model ResNet152 --batch 128 --caps 4,8,16,25,50,100,200
+
+From a plain shell the script starts its N ranks itself (one per GPU, like ``bench.py --gpus N``: the parent makes no
+GPU call and relays rank 0's lines); under a launcher that has set RANK / WORLD_SIZE / MASTER_* (``python -m
+torch.distributed.run --nproc-per-node N ... bench/bucket_sweep.py``) it is one of the ranks.  ``--cfg-filepath`` takes
+model, SyncBN switch and per-GPU batch from a trainer YAML (``config/ResNet101-large-batch.yml``, ...).
 
 For every bucket cap it builds a fresh engine, runs warm-up + timed steps and prints one JSON line
 (images/s, ms/step, number of buckets).  A ring all-reduce over point-to-point xGMI links is bound
@@ -19,8 +23,9 @@ import time
 import torch
 import torch.distributed as dist
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pytorch_distributed_training_amd.config import validate_cfg  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pytorch_distributed_training_amd.config import get_cfg, validate_cfg  # noqa: E402
 from pytorch_distributed_training_amd.engine.engines import build_engine  # noqa: E402
 from pytorch_distributed_training_amd.parallel import dist_env  # noqa: E402
 
@@ -34,7 +39,22 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=15)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--sync-bn", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks to start when no launcher has set the rendezvous variables")
+    ap.add_argument("--cfg-filepath", default="", help="trainer YAML: model, sync_bn and the per-GPU batch come from it")
     args = ap.parse_args()
+    if args.gpus > 1 and not dist_env.env_launch_detected():
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("pdt_bench", os.path.join(ROOT, "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)                       # (importing it touches no GPU)
+        return bench.self_launch(args.gpus, sys.argv[1:], script=os.path.abspath(__file__))
+    if args.cfg_filepath:
+        file_cfg = get_cfg(args.cfg_filepath)
+        tr = file_cfg["training"]
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        args.model = file_cfg["model"]["name"]
+        args.sync_bn = int(bool(tr.get("sync_bn", False)))
+        args.batch = int(tr.get("per_gpu_batch_size") or max(int(tr["batch_size"]) // max(world, 1), 1))
     info = dist_env.init_from_env("nccl") if dist_env.env_launch_detected() else \
         dist_env.init_distributed("nccl", None, 1, 0, 0, 1)
     dev = info.device

@@ -21,6 +21,7 @@ never sees a partial file.
 """
 from __future__ import annotations
 
+import logging
 import os
 import random
 from typing import Any, Dict, List, Optional
@@ -43,17 +44,44 @@ def _pack_rng() -> Dict[str, Any]:
     return out
 
 
-def _unpack_rng(state: Dict[str, Any]) -> None:
-    try:
+def _unpack_rng(state: Dict[str, Any], logger: Optional[logging.Logger] = None) -> bool:
+    """Restore the saved generator states; ``False`` (and a logged warning naming the part that failed) when one of them
+    could not be restored -- a resumed run then continues, but no longer reproduces the uninterrupted run's data order
+    and augmentation stream from here on."""
+    log = logger or logging.getLogger(__name__)
+    ok = True
+
+    def part(what: str, fn) -> None:
+        nonlocal ok
+        try:
+            fn()
+        except Exception as exc:                     # noqa: BLE001 -- one bad part must not stop the others
+            ok = False
+            log.warning("resume: the %s random-generator state of the checkpoint was NOT restored (%s: %s)", what,
+                        type(exc).__name__, exc)
+
+    def _py():
         py = state["python"]
         random.setstate((py[0], tuple(py[1]), py[2]))
+
+    def _np():
         n = state["numpy"]
         np.random.set_state((n["kind"], n["keys"].numpy().astype(np.uint32), n["pos"], n["has_gauss"], n["cached"]))
-        torch.set_rng_state(state["torch"].cpu())
-        if "cuda" in state and torch.cuda.device_count() == len(state["cuda"]) and torch.cuda.is_available():
-            torch.cuda.set_rng_state_all([s.cpu() for s in state["cuda"]])
-    except Exception:
-        pass  # RNG restore is best effort (e.g. different GPU count on resume)
+
+    def _cuda():
+        if not (torch.cuda.device_count() > 0 and torch.cuda.is_available()):
+            return
+        if torch.cuda.device_count() != len(state["cuda"]):
+            raise RuntimeError(f"checkpoint holds {len(state['cuda'])} GPU generator states, this process sees "
+                               f"{torch.cuda.device_count()} GPUs")
+        torch.cuda.set_rng_state_all([s.cpu() for s in state["cuda"]])
+
+    part("python", _py)
+    part("numpy", _np)
+    part("torch", lambda: torch.set_rng_state(state["torch"].cpu()))
+    if "cuda" in state:
+        part("GPU", _cuda)
+    return ok
 
 
 def _to_cpu(obj):
@@ -103,9 +131,11 @@ def load_checkpoint(path: str, map_location="cpu") -> Dict[str, Any]:
     return {"model": obj, "optimizer": None, "scheduler": None, "iter": 0, "rng": None, "config": None}
 
 
-def restore_rng(ckpt: Dict[str, Any]) -> None:
+def restore_rng(ckpt: Dict[str, Any], logger: Optional[logging.Logger] = None) -> bool:
+    """``True`` when every generator state of the checkpoint was restored (or it holds none)."""
     if ckpt.get("rng"):
-        _unpack_rng(ckpt["rng"])
+        return _unpack_rng(ckpt["rng"], logger)
+    return True
 
 
 def latest_checkpoint(directory: str) -> Optional[str]:
@@ -124,20 +154,26 @@ def latest_checkpoint(directory: str) -> Optional[str]:
     return best
 
 
-def prune_checkpoints(directory: str, keep: int) -> List[str]:
+def prune_checkpoints(directory: str, keep: int, upto: Optional[int] = None) -> List[str]:
     """Delete all but the ``keep`` newest periodic checkpoints (``iter_<n>.pth``) of ``directory``
     and return the removed paths.  Files with other names (explicitly tagged saves) stay.  A
     450 000-iteration run with a checkpoint every 2000 iterations would otherwise leave 225
-    full training states (~300 MB each for ResNet-50) behind."""
+    full training states (~300 MB each for ResNet-50) behind.
+
+    ``upto``: the iteration just saved.  Only checkpoints up to it count: files with a HIGHER iteration number are
+    left-overs of another run in a reused directory -- they are neither deleted nor allowed to push this run's own
+    checkpoints out of the newest ``keep`` (see :func:`stale_checkpoints`)."""
     if keep <= 0 or not directory or not os.path.isdir(directory):
         return []
     found = []
     for fn in os.listdir(directory):
         if fn.startswith("iter_") and fn.endswith(".pth"):
             try:
-                found.append((int(fn[5:-4]), os.path.join(directory, fn)))
+                it = int(fn[5:-4])
             except ValueError:
                 continue
+            if upto is None or it <= upto:
+                found.append((it, os.path.join(directory, fn)))
     found.sort()
     removed = []
     for _, path in found[:-keep]:
@@ -147,3 +183,18 @@ def prune_checkpoints(directory: str, keep: int) -> List[str]:
         except OSError:
             pass
     return removed
+
+
+def stale_checkpoints(directory: str, current_iter: int) -> List[str]:
+    """Periodic checkpoints of ``directory`` whose iteration lies beyond ``current_iter``: a fresh run pointed at a
+    directory another run has used.  ``resume: auto`` would pick the newest of them."""
+    out = []
+    if directory and os.path.isdir(directory):
+        for fn in os.listdir(directory):
+            if fn.startswith("iter_") and fn.endswith(".pth"):
+                try:
+                    if int(fn[5:-4]) > current_iter:
+                        out.append(os.path.join(directory, fn))
+                except ValueError:
+                    continue
+    return sorted(out)

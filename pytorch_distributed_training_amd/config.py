@@ -88,7 +88,7 @@ _SCHEMA: Dict[str, Any] = {
         "profile": (bool, False),              # roctx ranges around step phases
         "debug_sync_check": (int, 0),          # every N iters compare param hashes across ranks
         "collective_timeout_s": (int, 1800),
-        "xgmi_timeout_s": ((int, float), None),# bound of a wait inside the xGMI SyncBN exchange; default: collective_timeout_s
+        "xgmi_timeout_s": ((int, float), None),# bound of a wait inside the xGMI SyncBN exchange; default: min(60, collective_timeout_s)
         "deterministic": (bool, False),
         "hip_graphs": (bool, True),            # native engine on GPU: record the step once, then replay it
         "step_replay": (str, "list"),          # list (command list of stream launches) | graph (HIP graphs) | off

@@ -60,7 +60,11 @@ class NativeEngine:
             syncbn_comm=tr.get("syncbn_comm", "auto"),
             step_replay=rt.get("step_replay", "list"),
             grad_allreduce_dtype=tr.get("grad_allreduce_dtype", "fp32"),
-            xgmi_timeout_s=float(rt.get("xgmi_timeout_s") or rt.get("collective_timeout_s", 1800)),
+            # A wait inside the exchange is a kernel spinning on the GPU: it gets a bound of its own, far shorter than a
+            # library collective's (a dead peer must not hold every surviving GPU for half an hour before the status word
+            # flips).  The places where a rank is legitimately late by more than seconds -- rank 0 writing a checkpoint,
+            # the start of validation -- are fenced by host-side barriers in the trainer, not waited out in here.
+            xgmi_timeout_s=float(rt.get("xgmi_timeout_s") or min(60.0, float(rt.get("collective_timeout_s", 1800)))),
             logger=logger,
         )
         # Same-seed initialisation on every rank (upstream seeds every worker identically,
@@ -75,7 +79,17 @@ class NativeEngine:
         self.world = self.model.world
         import os
         env = os.environ.get("PDT_OPT_IN_BACKWARD")          # measurement override of the config key
-        if (tr.get("optimizer_in_backward", True) if env is None else env == "1"):
+        want = tr.get("optimizer_in_backward", True) if env is None else env == "1"
+        # The per-bucket update runs while backward is still going, which is only sound when backward never reads what
+        # the update writes.  The HIP data-gradient kernels read the TRANSPOSED weight copies (refreshed after the
+        # step); the PyTorch reference backend reads the forward weights -- the very slices the update rewrites -- so
+        # with it on a GPU (where the hook runs inside backward, on the communication stream or in line) the update
+        # waits for the end of backward.  On the CPU the reducer runs the hooks from finish(), after backward.
+        safe = not getattr(self.ops, "dgrad_reads_forward_weights", True) or self.device.type != "cuda"
+        if want and not safe and logger is not None:
+            logger.info("optimizer_in_backward: the %s backend's data gradients read the forward weights; the update "
+                        "runs after backward", getattr(self.ops, "name", "?"))
+        if want and safe:
             self.model.attach_optimizer(self.optimizer)
 
     def train_step(self, img: torch.Tensor, label: torch.Tensor) -> torch.Tensor:

@@ -60,6 +60,10 @@ class CommFailure(RuntimeError):
     """The in-kernel xGMI statistics exchange timed out: the step's results are poisoned (NaN)."""
 
 
+class StepReplayError(RuntimeError):
+    """Recording a step for replay failed at a point from which the step cannot be repeated."""
+
+
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
@@ -99,7 +103,7 @@ class NativeResNet:
                  sync_bn: bool = False, group=None, bucket_cap_mb: float = 25.0, first_bucket_mb: float = 1.0,
                  overlap_comm: bool = True, bn_momentum: float = 0.1, bn_eps: float = 1e-5,
                  hip_graphs: bool = False, syncbn_overlap: bool = False, syncbn_comm: str = "auto",
-                 step_replay: str = "list", grad_allreduce_dtype: str = "fp32", xgmi_timeout_s: float = 1800.0,
+                 step_replay: str = "list", grad_allreduce_dtype: str = "fp32", xgmi_timeout_s: float = 60.0,
                  logger: Optional[logging.Logger] = None) -> None:
         self.spec = spec
         self.device = torch.device(device)
@@ -1138,14 +1142,22 @@ class NativeResNet:
                 finally:
                     self._rec = None
                     program.finish()
-        except Exception as exc:                     # noqa: BLE001 -- fall back to the eager path
-            self.log.warning("step recording failed (%s: %s): this batch signature runs EAGERLY from now on "
-                             "(several times the host cost per step)", type(exc).__name__, exc)
+        except Exception as exc:                     # noqa: BLE001 -- fall back to the eager path where that is sound
             self.replay_failures += 1
             self._ctx.clear()
             self._saved.clear()
             self._deferred = None
             self._wgrad_keep.clear()
+            if self.optimizer_in_backward:
+                # The step died half way: the buckets launched before the exception have ALREADY been updated (weights,
+                # momentum, zeroed gradients), the others hold partial gradient sums.  Re-running the batch would update
+                # the first ones twice, and under data parallelism only this rank would do so.  There is no sound way on
+                # from here: end the job (the trainer keeps logs and checkpoints; resume from the last one).
+                raise StepReplayError(f"step recording failed mid-step with the per-bucket optimizer active "
+                                      f"({type(exc).__name__}: {exc}); the replica has taken a partial update") from exc
+            self.log.warning("step recording failed (%s: %s): this batch signature runs EAGERLY from now on "
+                             "(several times the host cost per step)", type(exc).__name__, exc)
+            self.params.g.zero_()                    # partial gradient sums of the aborted attempt
             return None
         return static_img, static_label, loss, program
 

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_fused_kernel(
     float* __restrict__ rvar, float momentum, float eps, float unbias, float* __restrict__ scale,
     float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out, int C, int nrep) {
     __shared__ float vals[CAR_MAX_FLOATS];
-    __shared__ unsigned ctl[2];
+    __shared__ unsigned ctl[CAR_CTL_WORDS];
     for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
         vals[i] = acc_take(acc + i, (size_t)2 * C, nrep) * inv_count;
     }
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_sums_fused_kernel(const CarDev ca
                                                                   float* __restrict__ sums, float* __restrict__ dgamma,
                                                                   float* __restrict__ dbeta, int C, int nrep) {
     __shared__ float vals[CAR_MAX_FLOATS];
-    __shared__ unsigned ctl[2];
+    __shared__ unsigned ctl[CAR_CTL_WORDS];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const float is = invstd[c];
         const float db = dbeta ? dbeta[c] : 0.0f, dg = dgamma ? dgamma[c] : 0.0f;

@@ -3,7 +3,7 @@
 
 __global__ __launch_bounds__(1024) void car_allreduce_kernel(const CarDev d, float* __restrict__ data, int n) {
     __shared__ float vals[CAR_MAX_FLOATS];
-    __shared__ unsigned ctl[2];
+    __shared__ unsigned ctl[CAR_CTL_WORDS];
     for (int i = threadIdx.x; i < n; i += blockDim.x) vals[i] = data[i];
     __syncthreads();
     car_exchange_block(d, vals, n, ctl);            // after a timeout: NaN everywhere, status set
@@ -52,6 +52,7 @@ PDT_API int pdt_car_create(int world, int rank, int max_floats, void** out) {
     h->dev.peer_flags[rank] = h->dev.flags;
     h->dev.peer_recv[rank] = h->dev.recv;
     h->dev.timeout_ticks = 200000000LL;           // 2 s of the 100 MHz wall clock
+    h->dev.corrupt = 0u;
     *out = h;
     return 0;
 }
@@ -85,6 +86,15 @@ PDT_API int pdt_car_set_timeout_ms(void* handle, int ms) {
     CarHost* h = static_cast<CarHost*>(handle);
     if (!h || ms < 1) return -2;
     h->dev.timeout_ticks = (long long)ms * 100000LL;
+    return 0;
+}
+
+// Test hook: from now on this rank sends checksums XORed with ``mask`` (0: back to normal).  A receiver must then refuse
+// the payload (status 2, NaN result) after its bounded re-reads.
+PDT_API int pdt_car_corrupt_checksum(void* handle, unsigned mask) {
+    CarHost* h = static_cast<CarHost*>(handle);
+    if (!h) return -2;
+    h->dev.corrupt = mask;
     return 0;
 }
 

@@ -18,6 +18,8 @@ from . import build as _build
 from .ref import MASK_NONE, MASK_RECOMPUTE, MASK_TENSOR  # noqa: F401  (re-exported)
 
 name = "hip"
+# conv_dgrad reads the transposed copies ``wt`` only: the forward weights may be updated while backward still runs
+dgrad_reads_forward_weights = False
 needs_wt = True
 NREP = 16
 
@@ -71,6 +73,7 @@ _sig("pdt_car_create", _i, _i, _i, ctypes.POINTER(ctypes.c_void_p))
 _sig("pdt_car_ipc_handle", _vp, _vp)
 _sig("pdt_car_open", _vp, _vp)
 _sig("pdt_car_set_timeout_ms", _vp, _i)
+_sig("pdt_car_corrupt_checksum", _vp, _i)
 _sig("pdt_car_allreduce", _vp, _vp, _i, _vp)
 _sig("pdt_car_query", _vp, _vp)
 _sig("pdt_car_peek", _vp)
@@ -233,9 +236,15 @@ def _wgrad_workspace(device: torch.device, stream: int):
     return ws.data_ptr(), ws.numel() * 4
 
 
-def _accumulator(device: torch.device, C: int, kind: str) -> torch.Tensor:
-    """Persistent zero-initialised ``[NREP, 2, C]`` accumulator (kernels re-zero it after use)."""
-    key = (device.index or 0, C, kind)
+def _accumulator(device: torch.device, C: int, kind: str, per_stream: bool = False) -> torch.Tensor:
+    """Persistent zero-initialised ``[NREP, 2, C]`` accumulator (kernels re-zero it after use).
+
+    ``per_stream``: one buffer per issuing stream.  For the kinds that are filled AND consumed inside one call (the
+    "fold" scratch sums): such a call may come from the weight-gradient stream while another one with the same channel
+    count runs on the main stream, and two streams adding into and re-zeroing one buffer would mix their sums.  Kinds
+    that hand sums from one call to a later one (statistics, column sums) stay keyed by name: their producer and
+    consumer may sit on different streams, ordered by the engine's events."""
+    key = (device.index or 0, C, kind, int(_stream() or 0) if per_stream else None)
     acc = _acc_cache.get(key)
     if acc is None:
         acc = torch.zeros(NREP * 2 * C, dtype=torch.float32, device=device)
@@ -998,7 +1007,7 @@ def gram_and_means(a: torch.Tensor, colsum_slot: Optional[str] = None):
     if colsum_slot and not _deterministic:
         acc = _accumulator(dev, C, "colsum:" + colsum_slot)
     else:
-        acc = _accumulator(dev, C, "fold")
+        acc = _accumulator(dev, C, "fold", per_stream=True)
         _check(_lib.pdt_bn_stats_accum(_p(a), None, _p(acc), rows, C, _stream()), "pdt_bn_stats_accum")
     mom = torch.empty(2, C, dtype=torch.float32, device=dev)
     _check(_lib.pdt_bn_moments(_p(acc), _p(mom), C, 1.0 / rows, _stream()), "pdt_bn_moments")
@@ -1086,7 +1095,7 @@ def channel_sums(g: torch.Tensor) -> torch.Tensor:
     g = _bf16c(g, "channel_sums")
     C = g.shape[-1]
     rows = g.numel() // C
-    acc = _accumulator(g.device, C, "fold")
+    acc = _accumulator(g.device, C, "fold", per_stream=True)
     _check(_lib.pdt_bn_stats_accum(_p(g), None, _p(acc), rows, C, _stream()), "pdt_bn_stats_accum")
     out = torch.empty(2, C, dtype=torch.float32, device=g.device)
     _check(_lib.pdt_bn_moments(_p(acc), _p(out), C, 1.0, _stream()), "pdt_bn_moments")

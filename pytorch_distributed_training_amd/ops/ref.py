@@ -23,6 +23,8 @@ import torch
 import torch.nn.functional as F
 
 name = "ref"
+# conv_dgrad reads the forward weights ``w`` (an update of them must wait until backward is over)
+dgrad_reads_forward_weights = True
 
 MASK_NONE = 0       # dy = g
 MASK_TENSOR = 1     # dy = g * (mask_src > 0)

@@ -124,7 +124,7 @@ class XgmiAllReduce:
         """Collective: True on every rank iff no rank has seen a timeout."""
         return _agree(self.status(), dist.ReduceOp.MAX, self.group, self.device) == 0
 
-    def self_test(self, rounds: int = 48, production_timeout_s: float = 1800.0) -> bool:
+    def self_test(self, rounds: int = 48, production_timeout_s: float = 60.0) -> bool:
         """Collective: compare against the process group's all-reduce over many sizes and
         back-to-back calls (slot reuse, flag reuse); every rank returns the same verdict."""
         # Generous while testing: the first launch on a rank includes loading the code object, and
@@ -155,10 +155,10 @@ class XgmiAllReduce:
         dist.broadcast(ref, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
         ok = ok and bool(torch.equal(probe, ref)) and self.status() == 0
         agreed = _agree(1 if ok else 0, dist.ReduceOp.MIN, self.group, self.device) == 1
-        # In production a rank may legitimately arrive late (rank 0 writing a checkpoint, a cold
-        # file cache under a loader): wait as long as a library collective would
-        # (``runtime.xgmi_timeout_s``, by default the process group's own timeout), but not for
-        # ever -- a peer that never arrives must not leave a kernel spinning on the GPU.
+        # In production a rank may legitimately arrive late (a cold file cache under a loader): the wait
+        # is bounded by ``runtime.xgmi_timeout_s`` (a minute by default -- it is a kernel spinning on the
+        # GPU, so it is NOT given a library collective's half hour; the long host-side pauses, a
+        # checkpoint being written or validation starting, are fenced by barriers on the host).
         ms = os.environ.get("PDT_XGMI_TIMEOUT_MS")
         ms = int(ms) if ms else int(min(max(production_timeout_s, 1.0), 2.0e6) * 1000)
         self._lib.pdt_car_set_timeout_ms(self._h, ms)

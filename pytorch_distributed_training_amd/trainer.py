@@ -121,6 +121,7 @@ class Trainer:
         self.scheduler = get_scheduler(self.engine.optimizer, tr["lr_schedule"], train_iters=tr["train_iters"])
 
         self.ckpt_dir = tr.get("checkpoint_dir") or (os.path.join(log_dir, "checkpoints") if log_dir else None)
+        self._warned_stale = False
         self.ckpt_interval = tr.get("checkpoint_interval") or tr["val_interval"]
         resume = tr.get("resume")
         if resume == "auto":
@@ -141,7 +142,7 @@ class Trainer:
         if ck.get("scheduler"):
             self.scheduler.load_state_dict(ck["scheduler"])
         self.iter = int(ck.get("iter", 0))
-        ckpt_io.restore_rng(ck)
+        ckpt_io.restore_rng(ck, self.logger)
         self.logger.info("Resumed from %s at iteration %d", path, self.iter)
 
     def save_checkpoint(self, tag: Optional[str] = None) -> Optional[str]:
@@ -158,8 +159,14 @@ class Trainer:
             self.logger.info("Saved checkpoint %s", path)
             keep = int(self.cfg["training"].get("keep_last_checkpoints", 3) or 0)
             if tag is None and keep > 0:
-                for old in ckpt_io.prune_checkpoints(self.ckpt_dir, keep):
+                for old in ckpt_io.prune_checkpoints(self.ckpt_dir, keep, upto=self.iter + 1):
                     self.logger.info("Removed old checkpoint %s", old)
+                stale = ckpt_io.stale_checkpoints(self.ckpt_dir, self.iter + 1)
+                if stale and not self._warned_stale:
+                    self._warned_stale = True
+                    self.logger.warning("checkpoint directory %s holds %d checkpoint(s) from beyond iteration %d (another "
+                                        "run's, e.g. %s): they are left alone, and 'resume: auto' would pick the newest of "
+                                        "them", self.ckpt_dir, len(stale), self.iter + 1, os.path.basename(stale[-1]))
         if self.world > 1:
             # the other ranks wait here, on the host, rather than inside the next step's first
             # statistics exchange on the GPU

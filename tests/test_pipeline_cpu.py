@@ -60,6 +60,60 @@ def test_bench_self_launch_fails_fast_when_a_rank_dies(tmp_path, monkeypatch):
     assert time.monotonic() - t0 < 30          # the surviving rank was terminated, not waited for
 
 
+def test_bench_takes_the_trainer_yamls(monkeypatch):
+    """``bench.py --cfg-filepath``: the upstream-schema files name the benchmark configurations; the per-node batch of
+    the file is divided by the GPU count (reference train_distributed.py:191-195), explicit flags win."""
+    import argparse
+    import bench
+    ns = argparse.Namespace(gpus=4, steps=3, warmup=1, model="ResNet18", batch=1024, engine="native", sync_bn=0,
+                            bucket_cap_mb=25.0, image_size=224, input_format="uint8_nhwc")
+    cfg = bench.cfg_from_file(os.path.join(ROOT, "config", "ResNet50.yml"), ns, explicit=set())
+    assert (ns.model, ns.batch, ns.sync_bn) == ("ResNet50", 64, 1)
+    assert cfg["dataset"]["name"] == "synthetic" and cfg["training"]["per_gpu_batch_size"] == 64
+    assert cfg["training"]["batch_size"] == 256 and cfg["training"]["optimizer"]["lr"] == 0.1
+    ns2 = argparse.Namespace(**{**vars(ns), "gpus": 1, "batch": 512, "model": "X"})
+    bench.cfg_from_file(os.path.join(ROOT, "config", "test-sync.yml"), ns2, explicit={"batch"})
+    assert (ns2.model, ns2.batch) == ("ResNet50", 512)
+    big = [f for f in os.listdir(os.path.join(ROOT, "config")) if "large-batch" in f]
+    if big:
+        ns3 = argparse.Namespace(**{**vars(ns), "gpus": 8})
+        bench.cfg_from_file(os.path.join(ROOT, "config", big[0]), ns3, explicit=set())
+        assert ns3.batch >= 256                               # per_gpu_batch_size of the file, not batch_size / 8
+
+
+def test_rccl_start_up_log_summary():
+    import bench
+    log = "\n".join([
+        "h:1:1 [0] NCCL INFO RCCL version 2.22.3-HEAD",
+        "h:1:1 [0] NCCL INFO NCCL_MIN_NCHANNELS set by environment to 8.",
+        "h:1:1 [0] NCCL INFO comm 0x55 rank 0 nranks 8 cudaDev 0 busId 5000 commId 0xabc - Init START",
+        "h:1:1 [0] NCCL INFO Channel 00/16 :    0   1   2   3   4   5   6   7",
+        "h:1:1 [0] NCCL INFO Channel 01/16 :    0   3   2   1   4   7   6   5",
+        "h:1:1 [0] NCCL INFO Trees [0] 1/-1/-1->0->-1 [1] 3/-1/-1->0->-1",
+        "h:1:1 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC",
+        "h:1:1 [0] NCCL INFO 16 coll channels, 0 collnet channels, 0 nvls channels, 16 p2p channels, 2 p2p channels per peer",
+        "h:1:1 [0] NCCL INFO AllReduce: 26214400 Bytes -> Algo 1 proto 2 time 123.4", ""])
+    got = bench.parse_rccl_log(log)
+    assert got["version"].startswith("2.22") and got["nranks"] == 8 and got["channels"] == 16
+    assert got["coll_channels"] == 16 and got["p2p_channels_per_peer"] == 2
+    assert got["rings"] == ["0 1 2 3 4 5 6 7", "0 3 2 1 4 7 6 5"] and got["transports"] == ["P2P/IPC"]
+    assert got["env"] == {"NCCL_MIN_NCHANNELS": "8"}
+    assert got["choices"] == [{"collective": "AllReduce", "bytes": 26214400, "algo_proto": "ring/simple"}]
+    assert bench.parse_rccl_log("")["lines"] == 0             # nothing matched: no field but the size
+
+
+def test_bucket_sweep_starts_its_own_ranks(tmp_path, monkeypatch):
+    """bench/bucket_sweep.py --gpus N from a plain shell starts N interpreters of ITSELF with the rank environment."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench", "bucket_sweep.py"), "--gpus", "2", "--caps", "8",
+                          "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    # no GPU here: every rank reports that and exits 2 -> the launcher names both ranks and fails
+    assert res.returncode == 1, res.stdout + res.stderr
+    assert res.stderr.count("no GPU visible") == 2 and "ranks failed" in res.stderr
+
+
 # ----------------------------------------------------------------------------- optimizer in backward
 def _engine(n_classes=10, sync_bn=False, **kw):
     from pytorch_distributed_training_amd.engine import NativeResNet
@@ -170,6 +224,37 @@ def test_prune_checkpoints_keeps_newest_and_named(tmp_path):
     assert sorted(os.listdir(tmp_path)) == ["best.pth", "iter_10.pth", "iter_8.pth"]
     assert ckpt.prune_checkpoints(str(tmp_path), 0) == []
     assert ckpt.latest_checkpoint(str(tmp_path)).endswith("iter_10.pth")
+
+
+def test_prune_leaves_another_runs_checkpoints_alone(tmp_path):
+    """A fresh run in a reused directory: the stale files with higher iteration numbers are neither deleted nor allowed
+    to push the run's own checkpoints out of the newest ``keep``."""
+    from pytorch_distributed_training_amd import checkpoint as ckpt
+    for it in (400000, 402000):
+        (tmp_path / f"iter_{it}.pth").write_bytes(b"old")
+    for it in (2000, 4000, 6000):
+        (tmp_path / f"iter_{it}.pth").write_bytes(b"new")
+        removed = ckpt.prune_checkpoints(str(tmp_path), 2, upto=it)
+    assert [os.path.basename(p) for p in removed] == ["iter_2000.pth"]
+    assert sorted(os.listdir(tmp_path)) == ["iter_4000.pth", "iter_400000.pth", "iter_402000.pth", "iter_6000.pth"]
+    assert [os.path.basename(p) for p in ckpt.stale_checkpoints(str(tmp_path), 6000)] == ["iter_400000.pth", "iter_402000.pth"]
+    assert ckpt.stale_checkpoints(str(tmp_path), 500000) == []
+
+
+def test_rng_restore_reports_what_it_could_not_restore(caplog):
+    import logging
+    import random
+    from pytorch_distributed_training_amd import checkpoint as ckpt
+    state = ckpt._pack_rng() if hasattr(ckpt, "_pack_rng") else None
+    assert state is not None
+    random.random()
+    assert ckpt.restore_rng({"rng": state}) is True
+    broken = dict(state)
+    broken["numpy"] = {"kind": "MT19937"}                     # keys / pos missing
+    with caplog.at_level(logging.WARNING):
+        assert ckpt.restore_rng({"rng": broken}, logging.getLogger("t")) is False
+    assert any("numpy" in r.getMessage() and "NOT restored" in r.getMessage() for r in caplog.records)
+    assert ckpt.restore_rng({"rng": None}) is True
 
 
 # ----------------------------------------------------------------------------- augmentation streams
