@@ -253,8 +253,9 @@ PDT_API int pdt_bnfold_sums(const float* prod, const void* w, const float* s0, c
     return pdt_launch_status();
 }
 
-// acc row 0: sum_m (y - s) = W[n].cs - rows s_n ;  sum_m (y - s)^2 = W[n] G W[n]^T - 2 s_n W[n].cs + rows s_n^2
-// (y = a W^T, cs = colsum(a) = rows * amean, G = a^T a).  One block per 32 channels n; its four waves split the
+// acc row 0: sum_m (y - s) = rows (W[n].amean - s_n) ;  sum_m (y - s)^2 = W[n] Gc W[n]^T + rows (W[n].amean - s_n)^2
+// (y = a W^T, G = a^T a, Gc = G - rows amean amean^T: the CENTRED Gram matrix, so that the variance is a quadratic form
+// of its own and not the difference of two numbers ~ mean^2).  One block per 32 channels n; its four waves split the
 // 32-column tiles of W.G, each element of which is multiplied by W[n][c] and added up over c.
 __global__ __launch_bounds__(256) void bnfold_fwd_stats_kernel(const bf16* __restrict__ w, const float* __restrict__ gram,
                                                                 const float* __restrict__ amean, float rows,
@@ -270,14 +271,25 @@ __global__ __launch_bounds__(256) void bnfold_fwd_stats_kernel(const bf16* __res
     const bf16* pa = w + (size_t)(n0 + r) * C + 8 * h;
     for (int ct = wave; ct < C / 32; ct += 4) {
         const float* pg = gram + (size_t)(32 * ct + r) * C + 8 * h;          // G[c][c'] stands in for G[c'][c]
+        const float* pm = amean + 8 * h;
+        const float mr = rows * amean[32 * ct + r];
         f32x16 t;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t[i] = 0.f;
 #pragma unroll 4
         for (int s = 0; s < C / 16; ++s) {
             const bf16x8 av = *reinterpret_cast<const bf16x8*>(pa + 16 * s);
-            const f32x4 g0 = *reinterpret_cast<const f32x4*>(pg + 16 * s);
-            const f32x4 g1 = *reinterpret_cast<const f32x4*>(pg + 16 * s + 4);
+            f32x4 g0 = *reinterpret_cast<const f32x4*>(pg + 16 * s);
+            f32x4 g1 = *reinterpret_cast<const f32x4*>(pg + 16 * s + 4);
+            const f32x4 m0 = *reinterpret_cast<const f32x4*>(pm + 16 * s);
+            const f32x4 m1 = *reinterpret_cast<const f32x4*>(pm + 16 * s + 4);
+            // centred BEFORE the split into bf16 pairs: with |mean| >> sigma the raw entries are all ~ rows mean^2 and
+            // the 16 bits a pair keeps would be spent on that offset (0.5 % variance error at 30 sigma)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                g0[k] = fmaf(-mr, m0[k], g0[k]);
+                g1[k] = fmaf(-mr, m1[k], g1[k]);
+            }
             bf16x8 hi, lo;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -321,11 +333,10 @@ __global__ __launch_bounds__(256) void bnfold_fwd_stats_kernel(const bf16* __res
     __syncthreads();
     if (tid < 32) {
         const int n = n0 + tid;
-        const float quad = red[0][0][tid] + red[0][1][tid] + red[0][2][tid] + red[0][3][tid];
-        const float lin = red[1][0][tid] * rows;          // sum_m y
-        const float sh = shift ? shift[n] : 0.f;
-        acc[n] = lin - rows * sh;
-        acc[N + n] = quad - 2.f * sh * lin + rows * sh * sh;
+        const float quad = red[0][0][tid] + red[0][1][tid] + red[0][2][tid] + red[0][3][tid];   // sum_m (y - mean y)^2
+        const float off = red[1][0][tid] - (shift ? shift[n] : 0.f);                                // mean y - s
+        acc[n] = rows * off;
+        acc[N + n] = fmaf(rows * off, off, quad);
     }
 }
 

@@ -399,9 +399,10 @@ def bn_stats_from_gram(w: torch.Tensor, gram: torch.Tensor, mom: torch.Tensor, r
     N, C = w.shape[0], w.shape[-1]
     w2 = w.reshape(N, C).float()
     mean = w2 @ mom[0]
-    ey2 = ((w2 @ (gram / rows)) * w2).sum(1)
-    s = stat_shift if stat_shift is not None else torch.zeros_like(mean)
-    return torch.stack([mean - s, ey2 - 2 * s * mean + s * s])
+    # centred first: the variance as a quadratic form of its own, not the difference of two numbers ~ mean^2
+    var = ((w2 @ (gram / rows - torch.outer(mom[0], mom[0]))) * w2).sum(1)
+    off = mean - stat_shift if stat_shift is not None else mean
+    return torch.stack([off, var + off * off])
 
 
 def bn_fuse_fprop_weights(w, scale, shift, w2=None, scale2=None, shift2=None):

@@ -297,6 +297,63 @@ def test_hip_fused_block_tail(hip, device, shape):
     assert torch.equal(ref._unpack_bits(bits), out > 0)
 
 
+def _adversarial_layer(device, rows=4096, C=256, N=256, ratio=30.0, seed=3):
+    """Inputs whose every channel has |mean| = ``ratio`` sigma, and filters that carry the offset into the outputs
+    (sum of a filter's taps = 1, norm ~ 1): the outputs have |mean| ~ ``ratio`` sigma too."""
+    g = torch.Generator().manual_seed(seed)
+    a = (ratio + torch.randn(rows, C, generator=g)).to(torch.bfloat16)
+    w = torch.randn(N, C, generator=g) / C ** 0.5
+    w = (w + (1.0 - w.sum(1, keepdim=True)) / C).to(torch.bfloat16)
+    y = a.double() @ w.double().t()
+    return a.to(device).reshape(1, rows, 1, C), w.to(device).reshape(N, 1, 1, C), y.mean(0), y.var(0, unbiased=False)
+
+
+def _moments_to_mean_var(mom, shift):
+    m1, m2 = mom[0].double().cpu(), mom[1].double().cpu()
+    return m1 + shift.double().cpu(), m2 - m1 * m1
+
+
+GRAM_SHIFTS = ["fresh", "stale", "none", "opposite"]
+
+
+def _gram_shift(kind, mean):
+    # fresh: the running mean has converged; stale: it lags by 3 sigma; none: no shift; opposite: as wrong as it gets
+    return {"fresh": mean.float(), "stale": mean.float() - 3.0, "none": None, "opposite": -mean.float()}[kind]
+
+
+@pytest.mark.parametrize("kind", GRAM_SHIFTS)
+def test_gram_statistics_with_a_large_mean_reference(kind):
+    """Adversarial conditioning for the statistics that never see ``y``: E[y^2] - E[y]^2 from an UNCENTRED Gram matrix
+    cancels ~900:1 at |mean| = 30 sigma.  The fp32 reference ops must still give the variance to 1 %."""
+    dev = torch.device("cpu")
+    a, w, mean, var = _adversarial_layer(dev)
+    assert 20 < (mean.abs() / var.sqrt()).median() < 45
+    shift = _gram_shift(kind, mean)
+    gram, am = ref.gram_and_means(a)
+    mom = ref.bn_stats_from_gram(w, gram, am, a.shape[1], shift)
+    got_mean, got_var = _moments_to_mean_var(mom, shift if shift is not None else torch.zeros_like(mean))
+    assert ((got_mean - mean).abs() / var.sqrt()).max() < 1e-2
+    assert ((got_var - var).abs() / var).max() < 1e-2, ((got_var - var).abs() / var).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", GRAM_SHIFTS)
+def test_hip_gram_statistics_with_a_large_mean(hip, device, kind):
+    """The same on the kernels (Gram matrix by the weight-gradient kernel, bf16 hi/lo split of its entries in the
+    quadratic form, centred before the split): mean to 0.1 % of sigma, variance to 0.2 %, whatever the shift."""
+    a, w, mean, var = _adversarial_layer(device)
+    shift = _gram_shift(kind, mean)
+    shift_d = shift.to(device) if shift is not None else None
+    gram, am = hip.gram_and_means(a)
+    st = hip.bn_stats_from_gram(w, gram, am, a.shape[1], shift_d)
+    mom = hip.stats_to_moments(st)
+    got_mean, got_var = _moments_to_mean_var(mom, shift if shift is not None else torch.zeros_like(mean))
+    e_mean = ((got_mean - mean).abs() / var.sqrt()).max().item()
+    e_var = ((got_var - var).abs() / var).max().item()
+    print(f"gram statistics at |mean| = 30 sigma, shift {kind}: mean error {e_mean:.2e} sigma, variance error {e_var:.2e}")
+    assert e_mean < 1e-3 and e_var < 2e-3, (e_mean, e_var)
+
+
 @pytest.mark.gpu
 def test_hip_subsample2(hip, device):
     x = torch.randn(3, 10, 6, 64, device=device).to(torch.bfloat16)
