@@ -16,6 +16,7 @@ from typing import Iterator, Optional, Tuple
 import torch
 from torch.utils.data import DataLoader, Dataset
 
+from ..parallel import streams
 from ..parallel.sampler import DistributedShardSampler
 
 
@@ -88,7 +89,9 @@ class DevicePrefetcher:
         self.transform = transform
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
-        self.stream: Optional[torch.cuda.Stream] = torch.cuda.Stream(device=self.device) if self.cuda else None
+        # a stream of its own in a one-rank job; in a multi-rank RCCL job the copy rides on the communication stream (the
+        # rank's fourth stream is RCCL's: see parallel/streams.py)
+        self.stream: Optional[torch.cuda.Stream] = streams.get("copy", self.device) if self.cuda else None
         self._next: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._event = None
         self._preload()

@@ -43,6 +43,7 @@ import torch.distributed as dist
 from ..models.resnet import BlockSpec, ConvBNSpec, ResNetSpec
 from ..ops import ref as _ref
 from ..parallel import collectives as coll
+from ..parallel import streams
 from ..parallel.reducer import GradReducer
 from ..utils.profiling import trace_range
 from .params import FlatParams, make_buckets
@@ -173,6 +174,19 @@ class NativeResNet:
                 x = None
             self._xgmi = x
             self.syncbn_comm = "xgmi" if x is not None else "rccl"
+        # One-GPU rehearsal of a multi-rank job (several ranks share the card over a gloo group): the gradient buckets can
+        # go through a second instance of the exchange instead of gloo's host staging -- a kernel on the communication
+        # stream that ends only when the peer's matching kernel runs, which is how an RCCL all-reduce behaves (RCCL itself
+        # refuses two ranks on one device: "Duplicate GPU detected").  tests/test_stream_budget_gpu.py drives it.
+        self._bucket_xgmi = None
+        if os.environ.get("PDT_BUCKETS_OVER_XGMI") == "1" and self.device.type == "cuda" and dist.is_initialized() \
+                and getattr(ops, "name", "") == "hip":
+            from ..parallel.xgmi_allreduce import XgmiAllReduce
+            x = XgmiAllReduce.create(group, self.device)
+            if x is None or not x.self_test(production_timeout_s=xgmi_timeout_s):
+                raise RuntimeError("PDT_BUCKETS_OVER_XGMI=1: the exchange is not available between these ranks")
+            self._bucket_xgmi = x
+            coll.set_device_rendezvous(x, group)
         # Fused statistics path: the conv leaves its statistics in the accumulator and ONE kernel
         # does fold + rank exchange + finalize (needs the in-kernel exchange when SyncBN is on).
         self._fused_stats = bool(getattr(ops, "fused_finalize", False)) and self.device.type == "cuda" \
@@ -239,7 +253,7 @@ class NativeResNet:
         if want_ws and self.device.type == "cuda" and getattr(ops, "name", "") == "hip":
             # PDT_WGRAD_PRIO: stream priority of the weight-gradient stream (HIP: lower value = served first)
             prio = os.environ.get("PDT_WGRAD_PRIO")
-            self._wgrad_stream = torch.cuda.Stream(device=self.device, **({"priority": int(prio)} if prio else {}))
+            self._wgrad_stream = streams.get("wgrad", self.device, int(prio) if prio else None)
             self._fork_event, self._join_event = ops.new_event(), ops.new_event()
         # With an overlapped reducer the communication stream waits for the weight-gradient stream at every bucket;
         # otherwise the main stream joins it there itself.  PDT_WGRAD_JOIN=1 forces the joins (A/B measurements).
@@ -420,20 +434,20 @@ class NativeResNet:
         """Has an in-kernel statistics exchange of THIS rank timed out?  Reads a pinned host word
         the kernel writes: no synchronisation, cheap enough for every step; it may lag the GPU
         by the steps still queued."""
-        return self._xgmi is not None and self._xgmi.peek() != 0
+        return any(x is not None and x.peek() != 0 for x in (self._xgmi, self._bucket_xgmi))
 
     def raise_on_comm_failure(self) -> None:
         """Fail fast: a timed-out exchange produced NaN statistics (by construction, never stale
         memory), so the replica is unusable; the job must end and resume from a checkpoint."""
         if self.comm_failed():
-            raise CommFailure("the xGMI SyncBatchNorm exchange timed out (a peer rank is gone or stalled beyond "
+            raise CommFailure("an xGMI exchange timed out or failed its checksum (a peer rank is gone or stalled beyond "
                               "runtime.xgmi_timeout_s); this replica's state is poisoned -- resume from the last "
                               "checkpoint")
 
     def check_comm_health(self) -> bool:
         """Collective and synchronising: True on every rank iff no rank has seen a timeout.  Run
         before anything is persisted (a checkpoint must not capture poisoned weights)."""
-        return self._xgmi is None or self._xgmi.healthy()
+        return all(x.healthy() for x in (self._xgmi, self._bucket_xgmi) if x is not None)
 
     def _bn_train(self, u: ConvBNSpec, ctx: _UnitCtx, stats, n_local: int) -> None:
         """``stats``: what the conv returned -- a moments tensor, or (fused backends) the pending
@@ -1178,7 +1192,7 @@ class NativeResNet:
         from .graphs import StepProgram
         static_img, static_label = img.clone(), label.clone()
         cur = torch.cuda.current_stream(self.device)
-        side = torch.cuda.Stream(device=self.device)
+        side = streams.get("capture", self.device)
         side.wait_stream(cur)
         program = StepProgram(self.device)
         loss = None

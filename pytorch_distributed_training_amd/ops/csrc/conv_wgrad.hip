@@ -42,6 +42,8 @@ static const int g_pdt_wgrad_big_tile = env_int("PDT_WGRAD_BIG_TILE", 1);      /
 // layers with 64 channels on ONE side: 1 = a tile that is 128 wide on the other side (the 64-wide operand is read twice
 // per 128 instead of twice per 64 channels of the other one), 0 = 64 x 64
 static const int g_pdt_wgrad_wide_small = env_int("PDT_WGRAD_WIDE_SMALL", 1);
+// 3x3 / stride 1 / padding 1: one kernel row per workgroup with the gathered operand staged once (0: one tap per workgroup)
+static const int g_pdt_wgrad_row3 = env_int("PDT_WGRAD_ROW3", 1);
 
 #define MAX_TAPS 52
 #define BKP 64   // pixels per K step
@@ -61,6 +63,7 @@ struct WgradParams {
     long long rows_per_split;
     int step_b, step_y, step_x;        // BKP GEMM rows as (images, grid rows, grid columns): see row_advance
     int use_dma;                       // 128 x 128 tile: LDS-DMA staging (needs 16-byte aligned pixel rows)
+    int lp;                            // wgrad_row3_kernel: log2 of the positions per image row
     const float* row_scale;            // [N] factor on output row n (null: 1): dW of a per-channel scaled dY without
                                        // ever forming that tensor (folded BatchNorm backward, bn_fold.hip)
     // one 32-bit word per tap: offy (int8) | offx (int8) << 8 | widx (uint16) << 16.  Sub-dword
@@ -69,7 +72,7 @@ struct WgradParams {
     int taps[MAX_TAPS];
 };
 
-__device__ __forceinline__ void unpack_tap(int w, int& oy, int& ox, int& widx) {
+__host__ __device__ __forceinline__ void unpack_tap(int w, int& oy, int& ox, int& widx) {
     oy = (int)(signed char)(w & 0xff);
     ox = (int)(signed char)((w >> 8) & 0xff);
     widx = (w >> 16) & 0xffff;
@@ -642,6 +645,216 @@ __global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(const WgradParams p)
     }
 }
 
+// 3x3 / stride 1 / padding 1: one workgroup owns one KERNEL ROW (three taps) of its (Cout tile, Cin tile, pixel slice)
+// and stages the gathered operand ONCE for the three taps.  With one tap per workgroup every dY tile and every X tile
+// crosses L2 -> LDS nine times, 64 FLOP per byte, and the kernel is bound by that traffic (and takes it from the critical
+// stream's kernels it runs beside); here a K step moves one dY tile and one X tile for three taps' worth of multiplies
+// (127 FLOP per byte at 128 x 64).
+//
+// The reduction index is not the output pixel but a POSITION on rows padded to a power of two: an image row of W pixels
+// occupies P >= W + 1 positions, q = 0 and q > W being padding (dY reads zero there, X reads zero there).  A K step of
+// 64 positions is 64 / P whole image rows, so tap ox = -1 / 0 / +1 multiplies dY[position] with X[position + ox]: the
+// SAME LDS tile read one row up or down (the transposing fragment read takes a per-lane row address, so the shift is an
+// address offset).  A pixel's left / right neighbour outside the image is the padding position next to it -- zero, as
+// the convolution's padding demands -- and the two rows beyond the tile's ends are only ever multiplied with dY's
+// padding positions (they are kept zero so that no stale NaN can meet a zero).  Rows above / below the image (oy = +-1)
+// are refused at load time, like in the gathering kernels.  With W = 7, 14, 28, 56 the padding costs 1/8 of the MFMA work.
+template <int BMO, int BNC, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void wgrad_row3_kernel(const WgradParams p) {
+    constexpr int RSA = (BMO + 16) * 2;
+    constexpr int RSB = (BNC + 16) * 2;
+    constexpr int A_BYTES = BKP * RSA, B_BYTES = (BKP + 2) * RSB;
+    constexpr int AV = BMO / 8, BV = BNC / 8;
+    constexpr int A_RPP = 256 / AV, B_RPP = 256 / BV;
+    constexpr int A_IT = BKP / A_RPP, B_IT = BKP / B_RPP;
+    constexpr int WTM = BMO / WM, WTN = BNC / WN;
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+    static_assert(2 * (A_BYTES + B_BYTES) <= 65536, "two LDS stages must fit the static limit");
+    static_assert(A_RPP <= BKP && BKP % A_RPP == 0 && B_RPP <= BKP && BKP % B_RPP == 0, "tile/thread mismatch");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int n_ct = (p.N + BMO - 1) / BMO;
+    const int n_cin = (p.Ci + BNC - 1) / BNC;
+    const int inner = 3 * n_cin;
+    const int nwg = p.splitk * n_ct * inner;
+    int wgid;
+    {
+        int orig = blockIdx.x;
+        int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int in_idx = wgid % inner;
+    const int rest = wgid / inner;
+    const int ct = rest % n_ct;
+    const int split = rest / n_ct;
+    const int krow = __builtin_amdgcn_readfirstlane(in_idx / n_cin);       // kernel row: oy = krow - 1
+    const int cin_tile = in_idx % n_cin;
+    const int co0 = ct * BMO, ci0 = cin_tile * BNC;
+    const int oy = krow - 1;
+    int wi_tap[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) wi_tap[t] = (p.taps[krow * 3 + t] >> 16) & 0xffff;
+
+    // positions: p.M of them, P = 1 << p.lp per image row
+    const int lp = p.lp, P = 1 << lp, W = p.Wi, H = p.Hi;
+    const unsigned r_begin = (unsigned)((long long)split * p.rows_per_split);
+    unsigned r_end = r_begin + (unsigned)p.rows_per_split;
+    if (r_end > (unsigned)p.M) r_end = (unsigned)p.M;
+    const int nk = r_begin < r_end ? (int)((r_end - r_begin + BKP - 1) / BKP) : 0;
+    if (nk == 0) return;
+
+    const int a_cv = tid % AV, a_row = tid / AV;
+    const int b_cv = tid % BV, b_row = tid / BV;
+    const bool a_col_ok = co0 + a_cv * 8 < p.N;
+    const bool b_col_ok = ci0 + b_cv * 8 < p.Ci;
+
+    // Whole tensors behind the descriptors: a slice is a whole number of K steps, positions past the last image are
+    // past the tensors' ends and read zeros.
+    const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(p.dy, p.dy_bytes);
+    const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(p.in, p.in_bytes);
+    bf16x8 a_reg0[A_IT], b_reg0[B_IT], a_reg1[A_IT], b_reg1[B_IT];
+    unsigned a_off[A_IT], b_off[B_IT];
+    int b_y[B_IT];
+    bool b_ok[B_IT];
+    const unsigned row0 = r_begin >> lp;                   // first image row (b * H + y) of the slice
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) {
+        const int pos = a_row + j * A_RPP, q = pos & (P - 1);
+        const unsigned rr = row0 + (unsigned)(pos >> lp);
+        const bool ok = a_col_ok && q >= 1 && q <= W;
+        a_off[j] = ok ? ((rr * (unsigned)W + (unsigned)(q - 1)) * (unsigned)p.ldy + co0 + a_cv * 8) * 2u : PDT_OOB_OFFSET;
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+        const int pos = b_row + j * B_RPP, q = pos & (P - 1);
+        const unsigned rr = row0 + (unsigned)(pos >> lp);
+        b_ok[j] = b_col_ok && q >= 1 && q <= W;
+        b_y[j] = (int)(rr % (unsigned)H);
+        // (rr + oy) * W + q - 1 may be "negative" for the very first row: refused by the row test below
+        b_off[j] = (((rr + (unsigned)oy) * (unsigned)W + (unsigned)(q - 1)) * (unsigned)p.pix_stride + ci0 + b_cv * 8) * 2u;
+    }
+    const int rows_step = BKP >> lp;                       // image rows per K step
+    const unsigned a_step = (unsigned)(rows_step * W * p.ldy * 2);
+    const unsigned b_step = (unsigned)(rows_step * W * p.pix_stride * 2);
+    const int y_step = rows_step % H;
+
+    auto load_tiles = [&](bf16x8 (&a_reg)[A_IT], bf16x8 (&b_reg)[B_IT]) {
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            a_reg[j] = buf_ld_bf16x8(dy_rsrc, a_off[j]);
+            a_off[j] += a_off[j] == PDT_OOB_OFFSET ? 0u : a_step;
+        }
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            const bool ok = b_ok[j] && (unsigned)(b_y[j] + oy) < (unsigned)H;
+            b_reg[j] = buf_ld_bf16x8(in_rsrc, ok ? b_off[j] : PDT_OOB_OFFSET);
+            b_off[j] += b_step;
+            b_y[j] += y_step;
+            b_y[j] -= b_y[j] >= H ? H : 0;
+        }
+    };
+    auto store_tiles = [&](int buf, const bf16x8 (&a_reg)[A_IT], const bf16x8 (&b_reg)[B_IT]) {
+        unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
+        unsigned char* Bs = As + A_BYTES + RSB;            // row 0 of the X stage is the halo above the tile
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j)
+            *reinterpret_cast<bf16x8*>(As + (a_row + j * A_RPP) * RSA + a_cv * 16) = a_reg[j];
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j)
+            *reinterpret_cast<bf16x8*>(Bs + (b_row + j * B_RPP) * RSB + b_cv * 16) = b_reg[j];
+    };
+
+    // the halo rows of both stages stay zero for the whole kernel
+    for (int i = tid; i < 4 * (RSB / 4); i += 256) {
+        const int which = i / (RSB / 4), w = i % (RSB / 4);
+        unsigned char* Bs = smem + (which >> 1) * (A_BYTES + B_BYTES) + A_BYTES + ((which & 1) ? (BKP + 1) * RSB : 0);
+        reinterpret_cast<unsigned*>(Bs)[w] = 0u;
+    }
+
+    f32x4 acc[3][MI][NI];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+    const int trow0 = 4 * g + q4;
+    const int tcol = 4 * pp;
+
+    auto compute = [&](int buf) {
+        const unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
+        const unsigned char* Bs = As + A_BYTES + RSB;
+#pragma unroll
+        for (int kk = 0; kk < BKP / 32; ++kk) {
+            bf16x8 af[MI];
+            const int r0 = kk * 32 + trow0, r1 = r0 + 16;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                int col = wm * WTM + i * 16 + tcol;
+                af[i] = tr_read_pair(As + r0 * RSA + col * 2, As + r1 * RSA + col * 2);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                bf16x8 bfr[NI];
+                const unsigned char* Bt = Bs + (t - 1) * RSB;          // ox = t - 1: the tile one row up / down
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    int col = wn * WTN + j * 16 + tcol;
+                    bfr[j] = tr_read_pair(Bt + r0 * RSB + col * 2, Bt + r1 * RSB + col * 2);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[t][i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    load_tiles(a_reg0, b_reg0);                            // step 0
+    store_tiles(0, a_reg0, b_reg0);
+    if (nk > 1) load_tiles(a_reg0, b_reg0);                // step 1, in flight
+    __syncthreads();
+    for (int ks = 0; ks < nk; ks += 2) {
+        if (ks + 2 < nk) load_tiles(a_reg1, b_reg1);
+        compute(0);
+        if (ks + 1 >= nk) break;
+        store_tiles(1, a_reg0, b_reg0);
+        __syncthreads();
+        if (ks + 3 < nk) load_tiles(a_reg0, b_reg0);
+        compute(1);
+        if (ks + 2 < nk) store_tiles(0, a_reg1, b_reg1);
+        __syncthreads();
+    }
+
+    const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const long long wofs = (long long)wi_tap[t] * p.Ci;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                int c = ci0 + wn * WTN + j * 16 + frow;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int n = co0 + wm * WTM + i * 16 + fq * 4 + r;
+                    if (n < p.N && c < p.Ci) {
+                        const float v = p.row_scale ? acc[t][i][j][r] * p.row_scale[n] : acc[t][i][j][r];
+                        if (p.ws) p.ws[(long long)split * p.slab + (long long)n * p.wrow + wofs + c] = v;
+                        else atomicAdd(p.dw + (long long)n * p.wrow + wofs + c, v);
+                    }
+                }
+            }
+    }
+}
+
 // dw[n][widx(t)*Ci + c] += sum over slices (in slice order) of the slab entries
 __global__ __launch_bounds__(256) void wgrad_fold_kernel(const WgradParams p) {
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -722,9 +935,66 @@ static int launch_wgrad(WgradParams& p, hipStream_t s, int target_blocks, long l
     return launch_fold(p, s);
 }
 
+// 3x3, stride 1, padding 1 on a dense grid: true iff the tap list is that filter; on success the taps are reordered to
+// [kernel row][ox = -1, 0, +1] and lp / M / in_bytes describe the padded position space of wgrad_row3_kernel.
+static bool row3_applies(const WgradParams& p) {
+    if (p.T != 9 || p.IS != 1 || p.Hg != p.Hi || p.Wg != p.Wi || p.Wi + 1 > BKP) return false;
+    int seen = 0;
+    for (int i = 0; i < 9; ++i) {
+        int oy, ox, w;
+        unpack_tap(p.taps[i], oy, ox, w);
+        if (oy < -1 || oy > 1 || ox < -1 || ox > 1) return false;
+        seen |= 1 << ((oy + 1) * 3 + ox + 1);
+    }
+    return seen == 0x1ff;
+}
+
+template <int BMO, int BNC, int WM, int WN>
+static int launch_wgrad_row3(WgradParams& p, hipStream_t s, int target_blocks, long long atomic_budget_bytes,
+                             long long ws_slabs) {
+    if (!row3_applies(p)) return -6;
+    int ordered[9];
+    for (int i = 0; i < 9; ++i) {
+        int oy, ox, w;
+        unpack_tap(p.taps[i], oy, ox, w);
+        ordered[(oy + 1) * 3 + ox + 1] = p.taps[i];
+    }
+    for (int i = 0; i < 9; ++i) p.taps[i] = ordered[i];
+    int lp = 3;
+    while ((1 << lp) < p.Wi + 1) ++lp;
+    p.lp = lp;
+    const long long image_rows = p.M / p.Wg;               // B * H
+    const long long positions = image_rows << lp;
+    if (positions >= 0x7fffffffLL) return -2;
+    p.M = positions;
+    int n_ct = (p.N + BMO - 1) / BMO;
+    int n_cin = (p.Ci + BNC - 1) / BNC;
+    long long tiles = (long long)n_ct * n_cin * 3;
+    long long max_split = (p.M + 2 * BKP - 1) / (2 * BKP);
+    long long split = (target_blocks + tiles - 1) / tiles;
+    if (split > max_split) split = max_split;
+    long long out_bytes = (long long)p.N * p.T * p.Ci * 4;
+    long long budget_split = atomic_budget_bytes / (out_bytes > 0 ? out_bytes : 1);
+    if (budget_split < 1) budget_split = 1;
+    if (split > budget_split) split = budget_split;
+    if (p.ws && split > ws_slabs) split = ws_slabs;
+    if (split < 1) split = 1;
+    long long rps = (p.M + split - 1) / split;
+    rps = (rps + BKP - 1) / BKP * BKP;
+    split = (p.M + rps - 1) / rps;
+    p.splitk = (int)split;
+    p.rows_per_split = rps;
+    long long nwg = tiles * split;
+    if (nwg > 0x7fffffffLL) return -2;
+    hipLaunchKernelGGL((wgrad_row3_kernel<BMO, BNC, WM, WN>), dim3((unsigned)nwg), dim3(256), 0, s, p);
+    return launch_fold(p, s);
+}
+
 // tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 64x32 (one tap per workgroup), 4 = 128x64,
 //       5 = 64x32 with all 7 taps per workgroup (the stem; auto picks it for T == 7, Ci <= 32),
-//       6 / 7 = 64x64 / 128x64 with three taps (one kernel row) per workgroup, Ci <= 64; 9 = 64x128
+//       6 / 7 = 64x64 / 128x64 with three taps (one kernel row) per workgroup, Ci <= 64; 9 = 64x128;
+//       10 / 11 = 128x64 / 64x64 with one kernel row per workgroup and the gathered operand staged once (3x3, stride 1,
+//       padding 1 only; auto picks them there)
 // ws / ws_bytes: workspace of the deterministic variant (NULL: float atomics).  It must stay untouched by other
 // streams until this launch has finished: one workspace per stream that issues weight gradients.
 // row_scale: optional [N] factor applied to output row n before it is added to dw
@@ -765,6 +1035,7 @@ PDT_API int pdt_conv_wgrad_ex(const void* dy, const void* in, float* dw, long lo
     // tile 8 = tile 1 with LDS-DMA operand staging (the automatic choice where tile 1 would be picked and rows are
     // 16-byte aligned); a forced tile 1 keeps the register-staged kernel (A/B measurements)
     p.use_dma = 0;
+    p.lp = 0;
     const bool dma_ok = ldy % 8 == 0 && pix_stride % 8 == 0 && Ci % 8 == 0;
     if (tile == 8) {
         if (!dma_ok) return -4;
@@ -780,6 +1051,7 @@ PDT_API int pdt_conv_wgrad_ex(const void* dy, const void* in, float* dw, long lo
     const int auto_mb = images >= 1024 ? 32 : 24;
     long long budget = (long long)(atomic_budget_mb > 0 ? atomic_budget_mb
                                    : (g_pdt_wgrad_atomic_mb > 0 ? g_pdt_wgrad_atomic_mb : auto_mb)) << 20;
+    if (tile == 0 && g_pdt_wgrad_row3 && Ci >= 64 && row3_applies(p)) tile = N <= 64 ? 11 : 10;
     if (tile == 0) {
         if (Ci <= 32) tile = (T == 7) ? 5 : 3;
         else if (T == 9 && Ci <= 64) tile = (N <= 64) ? 6 : 7;    // 3x3 on 64 channels: one kernel row per workgroup
@@ -802,6 +1074,8 @@ PDT_API int pdt_conv_wgrad_ex(const void* dy, const void* in, float* dw, long lo
         case 6: return launch_wgrad_taps<64, 64, 2, 2, 3>(p, s, target_blocks, ws_slabs);
         case 7: return launch_wgrad_taps<128, 64, 2, 2, 3>(p, s, target_blocks, ws_slabs);
         case 9: return launch_wgrad<64, 128, 2, 2>(p, s, target_blocks, budget, ws_slabs);
+        case 10: return launch_wgrad_row3<128, 64, 2, 2>(p, s, target_blocks, budget, ws_slabs);
+        case 11: return launch_wgrad_row3<64, 64, 2, 2>(p, s, target_blocks, budget, ws_slabs);
         default: return -6;
     }
 }

@@ -10,6 +10,22 @@ __global__ __launch_bounds__(1024) void car_allreduce_kernel(const CarDev d, flo
     for (int i = threadIdx.x; i < n; i += blockDim.x) data[i] = vals[i];
 }
 
+// Any length: the tensor in pieces of ``chunk`` floats, one exchange per piece (each advances the sequence number).  After a
+// failed piece the remaining ones return at once (the status word is sticky), so the kernel always ends.
+__global__ __launch_bounds__(1024) void car_allreduce_chunks_kernel(const CarDev d, float* __restrict__ data, long long n,
+                                                                    int chunk) {
+    __shared__ float vals[CAR_MAX_FLOATS];
+    __shared__ unsigned ctl[CAR_CTL_WORDS];
+    for (long long off = 0; off < n; off += chunk) {
+        const int m = (int)(n - off < (long long)chunk ? n - off : (long long)chunk);
+        for (int i = threadIdx.x; i < m; i += blockDim.x) vals[i] = data[off + i];
+        __syncthreads();
+        car_exchange_block(d, vals, m, ctl);
+        for (int i = threadIdx.x; i < m; i += blockDim.x) data[off + i] = vals[i];
+        __syncthreads();
+    }
+}
+
 static size_t car_recv_offset() { return 4096; }   // flags live in the first page of the allocation
 
 PDT_API int pdt_car_create(int world, int rank, int max_floats, void** out) {
@@ -105,6 +121,17 @@ PDT_API int pdt_car_allreduce(void* handle, float* data, int n, hipStream_t stre
     for (int r = 0; r < h->dev.world; ++r)
         if (!h->dev.peer_recv[r]) return -3;       // peers not opened yet
     hipLaunchKernelGGL(car_allreduce_kernel, dim3(1), dim3(1024), 0, stream, h->dev, data, n);
+    return pdt_launch_status();
+}
+
+PDT_API int pdt_car_allreduce_chunks(void* handle, float* data, long long n, hipStream_t stream) {
+    CarHost* h = static_cast<CarHost*>(handle);
+    if (!h || !data || n < 1 || (reinterpret_cast<uintptr_t>(data) & 3)) return -2;
+    for (int r = 0; r < h->dev.world; ++r)
+        if (!h->dev.peer_recv[r]) return -3;
+    const int cap = h->dev.max4 * 4;
+    const int chunk = cap < CAR_MAX_FLOATS ? cap : CAR_MAX_FLOATS;
+    hipLaunchKernelGGL(car_allreduce_chunks_kernel, dim3(1), dim3(1024), 0, stream, h->dev, data, n, chunk);
     return pdt_launch_status();
 }
 

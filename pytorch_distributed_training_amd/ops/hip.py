@@ -75,6 +75,7 @@ _sig("pdt_car_open", _vp, _vp)
 _sig("pdt_car_set_timeout_ms", _vp, _i)
 _sig("pdt_car_corrupt_checksum", _vp, _i)
 _sig("pdt_car_allreduce", _vp, _vp, _i, _vp)
+_sig("pdt_car_allreduce_chunks", _vp, _vp, _ll, _vp)
 _sig("pdt_car_query", _vp, _vp)
 _sig("pdt_car_peek", _vp)
 _sig("pdt_car_destroy", _vp)

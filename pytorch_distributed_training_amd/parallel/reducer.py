@@ -38,6 +38,7 @@ import torch
 import torch.distributed as dist
 
 from . import collectives as coll
+from . import streams
 
 
 class GradReducer:
@@ -86,7 +87,7 @@ class GradReducer:
 
     def _ensure_streams(self) -> None:
         if self.is_cuda and self.overlap and self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(device=self.flat.device)
+            self._comm_stream = streams.get("comm", self.flat.device)
             self._ready_events = [torch.cuda.Event() for _ in self.buckets]
             self._done_events = [torch.cuda.Event() for _ in self.buckets]
         if self.is_cuda and self.overlap and len(self._producer_events) != len(self.buckets):

@@ -102,6 +102,18 @@ class XgmiAllReduce:
             raise RuntimeError(f"pdt_car_allreduce failed with status {rc}")
         self.calls += 1
 
+    def all_reduce_large(self, t: torch.Tensor) -> None:
+        """In-place SUM of a contiguous fp32 GPU tensor of ANY length: one kernel on the current stream that walks the
+        tensor in pieces of the exchange's capacity (one exchange per piece, one workgroup -- a latency path put to
+        work as a rendezvous collective for one-GPU rehearsals, not a bandwidth path)."""
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise TypeError("xgmi all_reduce_large: expected a contiguous fp32 GPU tensor")
+        from ..ops.hip import _stream
+        rc = self._lib.pdt_car_allreduce_chunks(self._h, t.data_ptr(), t.numel(), _stream())
+        if rc != 0:
+            raise RuntimeError(f"pdt_car_allreduce_chunks failed with status {rc}")
+        self.calls += 1
+
     def supports(self, t: torch.Tensor) -> bool:
         return t.dtype == torch.float32 and t.is_contiguous() and t.numel() % 4 == 0 and \
             t.numel() <= self.max_floats and t.data_ptr() % 16 == 0

@@ -1,8 +1,10 @@
 """GPU tier: the distributed code paths on ONE MI355X.
 
 Real multi-GPU RCCL runs need a multi-GPU node; what can be checked on one GPU:
-* two ranks sharing the GPU over gloo (GPU tensors): SyncBN + bucketed reducer with the side
-  stream / events give the same gradients as one process on the concatenated batch;
+* two ranks sharing the GPU over gloo (GPU tensors), deterministic kernels, a conditioned network: the bucketed
+  reducer gives the sum of the local gradients bit for bit; SyncBN over identical shards reproduces the one-process
+  run bit for bit; SyncBN over different shards matches one process on the whole batch within what bf16 costs there
+  and far closer than unreduced statistics;
 * a one-rank RCCL group with PDT_FORCE_COLLECTIVES=1: every SyncBN all-reduce and every
   gradient bucket really goes through RCCL on the communication stream, and the result is
   unchanged.
@@ -42,73 +44,6 @@ def _engine(sync_bn):
 def _data():
     g = torch.Generator().manual_seed(11)
     return torch.randn(16, 3, 64, 64, generator=g), torch.randint(0, 100, (16,), generator=g)
-
-
-def _worker(rank, world, port, out_dir):
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
-    eng = _engine(True)
-    eng.broadcast_state(0)
-    x, y = _data()
-    xs = x[rank * 8:(rank + 1) * 8].cuda()
-    ys = y[rank * 8:(rank + 1) * 8].cuda()
-    loss = eng.forward_backward(xs, ys)
-    torch.cuda.synchronize()
-    torch.save({"loss": loss.cpu(), "grads": (eng.params.g * eng.reducer.grad_scale).cpu(),
-                "rm": eng.running_mean.cpu(), "launched": eng.reducer.stats["launched"],
-                "n_buckets": len(eng.buckets)}, os.path.join(out_dir, f"rank{rank}.pt"))
-    dist.destroy_process_group()
-
-
-def test_two_ranks_one_gpu_gloo_syncbn_equivalence(tmp_path):
-    # Each rank is its own interpreter under a hard time limit: two processes contending for one
-    # GPU through gloo's host-staged copies is an arrangement that can stall on some hosts, and a
-    # stall must not take the whole GPU test run with it.
-    port = _free_port()
-    env = dict(os.environ)
-    env["PYTHONPATH"] = ROOT + os.pathsep + os.path.join(ROOT, "tests") + os.pathsep + env.get("PYTHONPATH", "")
-    procs = [subprocess.Popen([sys.executable, "-c",
-                               f"import test_dist_gpu as t; t._worker({r}, 2, {port}, {str(tmp_path)!r})"],
-                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-             for r in range(2)]
-    outs = []
-    try:
-        for pr in procs:
-            out, _ = pr.communicate(timeout=90)
-            outs.append(out)
-    except subprocess.TimeoutExpired:
-        for pr in procs:
-            pr.kill()
-        pytest.skip("two gloo ranks sharing one GPU did not finish within 90 s on this host")
-    if any(pr.returncode != 0 for pr in procs):
-        joined = "\n".join(outs)
-        if "gloo" in joined.lower() and ("cuda" in joined.lower() or "hip" in joined.lower()) and "support" in joined.lower():
-            pytest.skip("gloo cannot reduce GPU tensors on this build")
-        raise AssertionError(joined[-3000:])
-    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
-    assert r0["launched"] == r0["n_buckets"] >= 3
-    assert torch.equal(r0["grads"], r1["grads"]) and torch.equal(r0["rm"], r1["rm"])
-    single = _engine(False)
-    x, y = _data()
-    loss = single.forward_backward(x.cuda(), y.cuda())
-    ref_grads = single.params.g.cpu()
-    # SyncBN over 2 x 8 samples against plain BatchNorm over the 16, every gradient bucket on its own.
-    # The two forwards are the same arithmetic on statistics that differ in the last fp32 bit; a handful
-    # of bf16 roundings flip in the first block and the flips multiply layer by layer (measured with
-    # bench/diag/syncbn_diag2.py: 0 differing elements after the stem, 11 after layer1.0, 87 % of the
-    # tensor by layer4.1, batch statistics 0.5 % apart there), so the gradients of this random-init,
-    # batch-16 network agree to 4 % (classifier) .. 18 % (stem) and no better.  A dropped or mis-scaled
-    # bucket is an error of 50-100 % in that bucket; exactness of the reducer itself is tested on
-    # integer data below, SyncBN in fp32 to 2e-3 in tests/test_distributed_cpu.py.
-    errs = bucket_errors(r0["grads"], ref_grads, single.buckets)
-    assert max(errs) < BUCKET_TOL and errs[0] < 0.08, errs
-    assert abs(0.5 * (r0["loss"] + r1["loss"]).item() - loss.item()) < 2e-3 * abs(loss.item())
-    n_early = single._bn_off["layer1.1.bn2"][0]          # statistics of the layers before the flips spread
-    assert torch.allclose(r0["rm"][:n_early], single.running_mean.cpu()[:n_early], rtol=1e-3, atol=1e-5)
-    assert torch.allclose(r0["rm"], single.running_mean.cpu(), rtol=5e-2, atol=2e-3)
-
-
-BUCKET_TOL = 0.3
 
 
 def bucket_errors(grads, ref_grads, buckets):
@@ -171,6 +106,135 @@ def _run_ranks(fn_call, world, tmp_path, timeout=120, extra_env=None):
         pytest.skip(f"{world} ranks sharing one GPU did not finish within {timeout} s on this host")
     assert all(pr.returncode == 0 for pr in procs), "\n".join(outs)[-4000:]
     return outs
+
+
+# ------------------------------------------------------------------ exact and conditioned comparisons
+def save_conditioned_case(path, world, per_rank=32, H=128):
+    """ResNet-18 conditioned as in tests/test_engine_oracle_gpu.py (bf16 and fp32 agree tensor by tensor there), one probe
+    batch of ``world * per_rank`` images: written once by the test process, read by every rank."""
+    from test_engine_oracle_gpu import _batch, conditioned_state
+    dev = torch.device("cuda", 0)
+    spec, sd, proto = conditioned_state("ResNet18", dev, H, 64, 12)
+    img, label = _batch(proto, world * per_rank, 999, torch.device("cpu"))
+    torch.save({"sd": {k: v.cpu() for k, v in sd.items()}, "img": img, "label": label}, path)
+
+
+def conditioned_engine(case, device, sync_bn, comm="auto"):
+    from pytorch_distributed_training_amd.engine import NativeResNet
+    from pytorch_distributed_training_amd.models import get_spec
+    from pytorch_distributed_training_amd.ops import hip
+    eng = NativeResNet(get_spec("ResNet18", 1000), device, hip, torch.bfloat16, sync_bn=sync_bn, bucket_cap_mb=4.0,
+                       first_bucket_mb=0.25, syncbn_comm=comm)
+    eng.load_state_dict(case["sd"])
+    return eng
+
+
+def conditioned_worker(rank, world, port, out_dir, sync_bn, comm, backend, device_index, duplicate=False):
+    """One rank of a conditioned, DETERMINISTIC comparison: the local gradient of its shard (engine without a process
+    group), then the same shard through the distributed engine.  ``duplicate``: every rank takes shard 0."""
+    from pytorch_distributed_training_amd.ops import hip
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", device_index)
+    torch.cuda.set_device(dev)
+    hip.set_deterministic(True)
+    case = torch.load(os.path.join(out_dir, "case.pt"))
+    n = case["img"].shape[0] // world
+    first = 0 if duplicate else rank * n
+    xs, ys = case["img"][first:first + n].to(dev), case["label"][first:first + n].to(dev)
+    solo = conditioned_engine(case, dev, False)
+    solo.forward_backward(xs, ys)
+    local, local_rm = solo.params.g.clone(), solo.running_mean.cpu()
+    del solo
+    kw = {"device_id": dev} if backend == "nccl" else {}
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank, **kw)
+    eng = conditioned_engine(case, dev, sync_bn, comm)
+    eng.broadcast_state(0)
+    loss = eng.forward_backward(xs, ys)
+    torch.cuda.synchronize()
+    if backend == "nccl":
+        on_dev = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(on_dev, local)
+        gathered = [t.cpu() for t in on_dev]
+    else:
+        gathered = [torch.empty_like(local).cpu() for _ in range(world)]
+        dist.all_gather(gathered, local.cpu())
+    torch.save({"loss": loss.float().cpu(), "g_sum": eng.params.g.cpu(), "locals": gathered, "rm": eng.running_mean.cpu(),
+                "local_rm": local_rm, "launched": eng.reducer.stats["launched"], "buckets": list(eng.buckets),
+                "comm": eng.syncbn_comm if sync_bn else None}, os.path.join(out_dir, f"cond{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def check_exact_buckets(res, world):
+    """Without SyncBN the distributed engine does the local engine's work and sums: with deterministic kernels the result
+    IS the sum of the local gradients -- bit for bit with two ranks (a + b has one order), to fp32 rounding of the
+    summation order with more (a ring starts every chunk at another rank)."""
+    r0 = res[0]
+    assert r0["launched"] == len(r0["buckets"]) >= 3
+    for r in res[1:]:
+        assert torch.equal(r["g_sum"], r0["g_sum"])
+    if world == 2:
+        assert torch.equal(r0["g_sum"], r0["locals"][0] + r0["locals"][1])
+    else:
+        want = torch.stack(r0["locals"]).double().sum(0)
+        errs = [((r0["g_sum"][a:b].double() - want[a:b]).norm() / (want[a:b].norm() + 1e-30)).item() for a, b in r0["buckets"]]
+        assert max(errs) < 1e-6, errs
+
+
+def check_syncbn_of_identical_shards(res, world):
+    """Every rank holds the SAME shard: the statistics over the ranks are the shard's own (sums and counts both scale by
+    the world size, a power of two), so SyncBN must reproduce the one-process run of that shard BIT FOR BIT -- forward
+    statistics, running statistics, and every gradient (summed over the ranks: ``world`` times the local one).  A
+    count taken per rank instead of globally, a sum applied twice or a payload read from the wrong slot shows here."""
+    for r in res:
+        assert torch.equal(r["g_sum"], r["locals"][0] * world), \
+            bucket_errors(r["g_sum"] / world, r["locals"][0], r["buckets"])
+        assert torch.equal(r["rm"], r["local_rm"])
+
+
+def check_syncbn_against_single(res, case, world, tol=0.15):
+    """SyncBN over ``world`` shards against plain BatchNorm over the whole batch in one process, on the conditioned
+    network.  The two runs use statistics that differ in the last fp32 bit (another summation order), so bf16 roundings
+    flip here and there: on this network that noise is what bf16 itself costs against fp32 (cosine 0.995 = 10 % in the
+    norm, profiles/oracle_conditioning_r3.txt), which bounds how tight this can be: every bucket within ``tol`` AND at
+    most 0.6 of what per-rank BatchNorm (statistics NOT reduced) scores on the same data (measured: 0.3-0.5 of it; the
+    conditioning itself differs a little from run to run, worst bucket 0.08-0.12).
+    The exact half of the claim is check_syncbn_of_identical_shards."""
+    from pytorch_distributed_training_amd.ops import hip
+    r0 = res[0]
+    for r in res[1:]:
+        assert torch.equal(r["g_sum"], r0["g_sum"]) and torch.equal(r["rm"], r0["rm"])
+    dev = torch.device("cuda", 0)
+    hip.set_deterministic(True)
+    try:
+        single = conditioned_engine(case, dev, False)
+        loss = single.forward_backward(case["img"].to(dev), case["label"].to(dev))
+        want = single.params.g.cpu()
+    finally:
+        hip.set_deterministic(False)
+    errs = bucket_errors(r0["g_sum"] / world, want, r0["buckets"])
+    unsynced = bucket_errors(torch.stack(r0["locals"]).sum(0) / world, want, r0["buckets"])
+    print("per-bucket error against one process: SyncBN over", world, "ranks", [f"{e:.4f}" for e in errs],
+          "-- per-rank BatchNorm", [f"{e:.4f}" for e in unsynced])
+    assert max(errs) < tol, errs
+    assert all(e < 0.6 * u for e, u in zip(errs, unsynced)), (errs, unsynced)
+    mean_loss = sum(r["loss"].item() for r in res) / world
+    assert abs(mean_loss - loss.item()) < 1e-2 * abs(loss.item())
+    assert torch.allclose(r0["rm"], single.running_mean.cpu(), rtol=1e-2, atol=1e-3)
+
+
+@pytest.mark.parametrize("mode", ["buckets", "syncbn", "syncbn_identical_shards"])
+def test_two_ranks_one_gpu_conditioned_exact(tmp_path, mode):
+    save_conditioned_case(tmp_path / "case.pt", 2)
+    sync_bn, dup = mode != "buckets", mode == "syncbn_identical_shards"
+    _run_ranks(f"conditioned_worker({{rank}}, 2, {{port}}, {str(tmp_path)!r}, {sync_bn}, 'auto', 'gloo', 0, {dup})", 2,
+               tmp_path, timeout=200)
+    res = [torch.load(tmp_path / f"cond{r}.pt") for r in range(2)]
+    if mode == "buckets":
+        check_exact_buckets(res, 2)
+    elif dup:
+        check_syncbn_of_identical_shards(res, 2)
+    else:
+        check_syncbn_against_single(res, torch.load(tmp_path / "case.pt"), 2)
 
 
 def test_bucketed_reducer_is_exact_two_ranks_one_gpu(tmp_path):

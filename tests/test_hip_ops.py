@@ -127,7 +127,7 @@ def test_conv_launches_split_over_the_batch(hip, device, monkeypatch, k, stride,
     assert rel_err(split[4], whole[4]) < 1e-4
 
 
-@pytest.mark.parametrize("tile", [1, 2, 4, 8, 9])
+@pytest.mark.parametrize("tile", [1, 2, 4, 8, 9, 10, 11])
 def test_wgrad_tiles(hip, device, tile):
     torch.manual_seed(tile)
     x = rnd(3, 14, 14, 128, device=device)
@@ -153,6 +153,25 @@ def test_wgrad_three_taps_per_workgroup(hip, device, tile, Co, stride):
     hip.conv_wgrad(x, dy, 3, 3, stride, 1, dw, tile=tile)
     ref.conv_wgrad(x, dy, 3, 3, stride, 1, dw_ref)
     assert rel_err(dw, dw_ref) < 5e-3
+
+
+@pytest.mark.parametrize("tile", [0, 10, 11])
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(3, 7, 7, 64, 64), (2, 14, 14, 128, 128), (5, 28, 28, 64, 192), (1, 56, 56, 64, 64),
+                                         (3, 9, 5, 192, 72), (2, 3, 63, 64, 128), (37, 7, 7, 512, 512)])
+def test_wgrad_kernel_row_per_workgroup(hip, device, tile, B, H, W, Ci, Co):
+    """3x3 / stride 1 / padding 1 with the gathered operand staged once per kernel row: image rows padded to a power of two
+    positions (7 -> 8, 14 -> 16, 28 -> 32, 56 -> 64, and widths that leave several padding positions), position counts
+    that are no multiple of the K step, partial channel tiles, many slices."""
+    torch.manual_seed(B * 100 + W)
+    x = rnd(B, H, W, Ci, device=device)
+    dy = rnd(B, H, W, Co, device=device)
+    dw = torch.zeros(Co, 3, 3, Ci, dtype=torch.float32, device=device)
+    dw_ref = torch.zeros_like(dw)
+    hip.conv_wgrad(x, dy, 3, 3, 1, 1, dw, tile=tile)
+    ref.conv_wgrad(x, dy, 3, 3, 1, 1, dw_ref)
+    assert rel_err(dw, dw_ref) < 5e-3
+    hip.conv_wgrad(x, dy, 3, 3, 1, 1, dw, tile=tile, target_blocks=64)      # accumulates; another split
+    assert rel_err(dw, 2 * dw_ref) < 5e-3
 
 
 @pytest.mark.parametrize("fmt", ["float_nchw", "uint8_nhwc"])

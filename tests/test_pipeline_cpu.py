@@ -353,3 +353,37 @@ def test_list_program_host_actions(monkeypatch):
     prog.items.append((lambda: 3, ()))
     with pytest.raises(RuntimeError):
         prog.replay()
+
+
+def test_stream_budget_roles(monkeypatch):
+    """parallel/streams.py: one stream per role, the capture stream shares the weight-gradient slot, a fifth stream is
+    refused, and in a multi-rank RCCL job the input copy rides on the communication stream."""
+    import torch.distributed as dist
+
+    from pytorch_distributed_training_amd.parallel import streams
+
+    class FakeStream:
+        def __init__(self, device=None, priority=0):
+            self.device, self.priority = device, priority
+
+    monkeypatch.setattr(torch.cuda, "Stream", FakeStream)
+    dev = torch.device("cuda", 0)
+    streams.reset()
+    try:
+        w = streams.get("wgrad", dev, priority=-1)
+        assert w.priority == -1 and streams.get("wgrad", dev) is w and streams.get("capture", dev) is w
+        c, cp = streams.get("comm", dev), streams.get("copy", dev)
+        assert c is not cp and streams.count(dev) == 4 and sorted(streams.in_use(dev)) == ["comm", "compute", "copy", "wgrad"]
+        with pytest.raises(RuntimeError, match="stream budget exceeded"):
+            streams.get("another", dev)
+        # multi-rank RCCL job: RCCL owns the fourth stream
+        streams.reset()
+        monkeypatch.setattr(dist, "is_initialized", lambda: True)
+        monkeypatch.setattr(dist, "get_backend", lambda *a: "nccl")
+        monkeypatch.setattr(dist, "get_world_size", lambda *a: 8)
+        cp = streams.get("copy", dev)
+        assert streams.get("comm", dev) is cp
+        streams.get("wgrad", dev)
+        assert streams.count(dev) == 4 and "rccl" in streams.in_use(dev)
+    finally:
+        streams.reset()
