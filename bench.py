@@ -327,6 +327,9 @@ def main() -> int:
     rccl = None
     if rccl_log and info.rank == 0:
         try:
+            # the library writes its log through a buffered C stream of this process: push it out before reading
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
             texts = [open(f, errors="replace").read() for f in sorted(glob.glob(rccl_log + "*"))]
             rccl = parse_rccl_log("\n".join(texts)) if texts else {"lines": 0}
             rccl["log"] = rccl_log

@@ -1,4 +1,8 @@
-for b in 384 512 640 768 1024; do
-  line=$(timeout -k 10 170 python bench.py --batch $b --steps 12 --warmup 5 2>/dev/null | grep '^{' | tail -1)
-  python -c "import json,sys; j=json.loads(sys.argv[1]); print(sys.argv[2], j['value'], j['ms_per_step'], j['config']['peak_mem_gb'])" "$line" $b
-done
+# per-GPU batch sweep on one MI355X: model, batch, images/s, ms/step, peak GB of HBM in use by the process
+run() {
+  line=$(timeout -k 10 280 python bench.py --model $1 --batch $2 --steps $3 --warmup 4 2>/dev/null | grep '^{' | tail -1)
+  python -c "import json,sys; j=json.loads(sys.argv[1]); print(sys.argv[2], sys.argv[3], j['value'], j['ms_per_step'], j['config']['peak_mem_gb'], j['config'].get('step_replay'))" "$line" $1 $2 || return 1
+}
+for b in 256 512 1024 1536 2048 3072 4096; do run ResNet50 $b 10 || exit 1; done
+for b in 256 512 1024 2048 3072; do run ResNet101 $b 8 || exit 1; done
+for b in 512 1024 2048; do run ResNet152 $b 6 || exit 1; done

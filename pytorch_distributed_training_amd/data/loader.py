@@ -62,8 +62,10 @@ class _SeedWorker:
 
 
 def build_loader(dataset: Dataset, batch_size: int, num_workers: int, train: bool, world_size: int, rank: int,
-                 seed: int = 0, pin_memory: bool = True, pad_val: bool = False) -> DataLoader:
-    """Per-rank loader: shuffled + ``drop_last`` shards for training, ordered shards for validation."""
+                 seed: int = 0, pin_memory: bool = True, pad_val: bool = False, native: bool = True):
+    """Per-rank loader: shuffled + ``drop_last`` shards for training, ordered shards for validation.  Packed training
+    splits whose crop runs on the GPU get the native batch gatherer (``num_workers`` = its thread count, at least one)
+    unless ``native=False``; everything else a ``torch.utils.data.DataLoader``."""
     sampler = DistributedShardSampler(
         len(dataset), num_replicas=world_size, rank=rank, shuffle=train, seed=seed,
         drop_last=train, pad=pad_val if not train else False,
@@ -71,6 +73,12 @@ def build_loader(dataset: Dataset, batch_size: int, num_workers: int, train: boo
     transform = getattr(dataset, "transform", None)
     if hasattr(transform, "reseed"):
         transform.reseed(augmentation_seed(seed, rank, -1))
+    if train and native and getattr(dataset, "gpu_augment", False) and hasattr(dataset, "native_records"):
+        # whole stored records, cropped on the GPU: batches are gathered by native threads (see .native)
+        from . import native as native_mod
+        if native_mod.available():
+            return native_mod.NativeRecordLoader(dataset, batch_size, sampler, threads=max(1, num_workers), drop_last=True,
+                                                 pin=pin_memory)
     return DataLoader(
         dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers,
         pin_memory=pin_memory and torch.cuda.is_available(), drop_last=train,
@@ -106,8 +114,13 @@ class DevicePrefetcher:
             self._next = (img, label) if self.transform is None else self.transform(img, label)
             return
         with torch.cuda.stream(self.stream):
+            release = getattr(img, "pdt_release", None)
             img = img.to(self.device, non_blocking=True)
             label = label.to(self.device, non_blocking=True)
+            if release is not None:                  # a loader that reuses its pinned buffers: tell it when the copy is done
+                copied = torch.cuda.Event()
+                copied.record(self.stream)
+                release(copied)
             if self.transform is not None:
                 img, label = self.transform(img, label)
             self._event = torch.cuda.Event()

@@ -131,6 +131,13 @@ class PackedImageDataset(Dataset):
                                  shape=(self.n, self.side, self.side, 3))
         return self._mm
 
+    def native_records(self):
+        """``(path, n, record shape, labels)`` of the training records as they lie in the file: what the native batch
+        gatherer needs (:mod:`.native`).  Only whole-record items qualify (training split, crop on the GPU)."""
+        if not self.gpu_augment:
+            raise ValueError("only the GPU-augmented training split hands out whole records")
+        return os.path.join(self.dir, IMAGES), self.n, (self.side, self.side, 3), self.labels
+
     def __getitem__(self, i: int):
         from .datasets import to_output_format
 
