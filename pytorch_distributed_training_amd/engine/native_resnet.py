@@ -1147,6 +1147,11 @@ class NativeResNet:
         from .graphs import ListProgram
         program = ListProgram(self.device, self.ops)
         static_img, static_label = img.clone(), label.clone()
+        # The eager step before this one left its activations cached in the allocator's default pool, and the recording
+        # allocates the same amount again from its private pool: hand the cached blocks back to the driver first, or a
+        # batch sized for more than half of the HBM runs out of memory right here.
+        torch.cuda.synchronize(self.device)
+        torch.cuda.empty_cache()
         try:
             with torch.cuda.use_mem_pool(program.pool):
                 self._rec = program
