@@ -561,21 +561,10 @@ def _out_like(out: Optional[torch.Tensor], shape, device, what: str) -> torch.Te
         raise ValueError(f"{what}: out must be a contiguous bf16 GPU tensor of shape {tuple(shape)}")
     return out
 
-# Static per-shape tile selection (what upstream leaves to cudnn.benchmark autotuning): shapes on
-# which the 64x128 tile measured faster than the launcher's own choice at per-GPU batch 256
-# (bench/conv_layers.py --tile sweep).  Key: (op, Cin, Cout, k, stride, input H).  Only applied in
-# the measurement's regime (per-GPU batch 192..383: the 14x14 / 7x7 layers then have too few
-# 128x128 tiles to fill the chip evenly); at batch 512 the same sweep prefers the launcher's own
-# choice on every layer, and small batches use the launcher's heuristic too.
-_TILE_HINTS = {
-    ("fprop", 256, 256, 3, 2, 28): 5, ("fprop", 1024, 256, 1, 1, 14): 5, ("fprop", 256, 256, 3, 1, 14): 5,
-    ("dgrad", 128, 128, 3, 2, 56): 5, ("dgrad", 256, 256, 3, 2, 28): 5, ("dgrad", 256, 1024, 1, 1, 14): 5,
-    ("dgrad", 256, 256, 3, 1, 14): 5, ("dgrad", 1024, 2048, 1, 2, 14): 5,
-}
-
-
-def _tile_hint(op: str, B: int, Ci: int, Co: int, k: int, stride: int, H: int) -> int:
-    return _TILE_HINTS.get((op, Ci, Co, k, stride, H), 0) if 192 <= B < 384 else 0
+# Tile selection is the launchers' own (shape and grid-fill heuristics in conv_dma.hip / conv_igemm.hip /
+# conv_wgrad.hip): swept against every explicit tile per layer at batch 256, 512 and 1024 it is within 1.5 % of the
+# per-shape best (profiles/tile_table_r2.txt), so there is no per-shape table to keep in step with the kernels -- what
+# upstream leaves to cudnn.benchmark autotuning is a fixed rule here.  ``tile=`` stays as a measurement override.
 
 
 # --------------------------------------------------------------------------- convolution
@@ -592,8 +581,6 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, R: int, S: int, stride: int, pa
     y = _out_like(out, (B, Ho, Wo, Co), x.device, "conv_fprop")
     M = B * Ho * Wo
     acc = _accumulator(x.device, Co, acc_slot) if stat_shift is not None else None
-    if tile == 0 and R == S and Hi == Wi and not _USE_CONV_DMA:
-        tile = _tile_hint("fprop", B, Ci, Co, R, stride, Hi)
     _igemm(x, w, y, M, Hi, Wi, Ci, Ci, Ho, Wo, stride, Ho, Wo, 1, 0, 0, Co, Co, R * S * Ci, _fprop_taps(R, S, pad),
            stat_acc=acc, stat_shift=stat_shift, tile=tile)
     if acc is None:
@@ -628,8 +615,6 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, wt: torch.Tensor, in_shape, R:
         mask_src = relu_bits
     elif relu_mask is not None:
         mask_src = _bf16c(relu_mask, "conv_dgrad relu_mask")
-    if tile == 0 and R == S and Hi == Wi and not _USE_CONV_DMA:
-        tile = _tile_hint("dgrad", B, Ci, Co, R, stride, Hi)
     bstat = None
     if bwd_stats is not None:
         by, bmean, bscale, bshift, bmode = bwd_stats

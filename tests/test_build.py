@@ -59,3 +59,27 @@ def test_host_sanitizer_library_loads_and_its_host_code_runs_clean():
     assert res.returncode == 0 and "ASAN_PROBE_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
     with pytest.raises(ValueError):
         build.build(preset="tsan")
+
+
+def test_prefetched_epilogue_registers_are_untouched_until_their_wait(tmp_path):
+    """The convolution kernels that prefetch the next tile's epilogue operands request them with inline-assembly loads the
+    compiler cannot see landing.  Audit of the generated gfx950 code: between each group of requests and the wait that
+    names their destination registers, no instruction reads or writes one of them (a compiler-placed copy or spill
+    there would move bytes that have not arrived).  bench/diag/audit_prefetch_regs.py does the walk."""
+    import importlib.util
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    from pytorch_distributed_training_amd.ops import build as kbuild
+    asm = tmp_path / "conv_dma.s"
+    flags = [f for f in kbuild.FLAGS if f != "-fPIC"]
+    subprocess.run([hipcc, *flags, "-I", kbuild.CSRC, "-S", "--offload-device-only",
+                    os.path.join(kbuild.CSRC, "conv_dma.hip"), "-o", str(asm)], check=True, capture_output=True)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("audit_prefetch_regs", os.path.join(root, "bench", "diag", "audit_prefetch_regs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(str(asm)) == 0
