@@ -59,7 +59,8 @@ struct ConvDmaParams {
     const float* bstat_scale;
     const float* bstat_shift;
     int M, N;
-    unsigned in_bytes, wgt_bytes;
+    unsigned long long in_bytes;       // the gathered operand may exceed a descriptor's 2 GiB reach: rebased per tile
+    unsigned wgt_bytes;
     int Hi, Wi, pix_stride, Ci;        // input image, elements between two pixels, channels per tap
     int Hg, Wg, IS;                    // GEMM row (b, y, x) on the Hg x Wg grid; tap t reads pixel (y*IS + offy, x*IS + offx)
     int Ho, Wo, OS, oy0, ox0;          // ... and is written to output pixel (y*OS + oy0, x*OS + ox0)
@@ -72,7 +73,7 @@ struct ConvDmaParams {
     unsigned char* bits_out;           // packed [out > 0] of the stored result, one bit per element (may be null)
     int relu_out;                      // clamp the result at zero before it is stored
     int sums_only;                     // stat_acc receives plain per-channel sums of the result (row 1 is not defined)
-    unsigned in2_bytes;
+    unsigned long long in2_bytes;
     int Ci2, pix_stride2;
     int taps[DMA_MAX_TAPS];            // offy (int8) | offx (int8) << 8 | widx (uint16) << 16
 #ifdef PDT_DMA_DIAG
@@ -189,9 +190,13 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
     const int nk = p.T * kc + kc2;
     const int HgWg = p.Hg * p.Wg;
 
-    const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.in, p.in_bytes);
+    // The gathered operand is addressed with 32-bit offsets from a base that moves with the tile: the first image the
+    // tile's rows touch (second operand / linear launches: the tile's first pixel).  A tile reaches a few images at
+    // most, so the offsets stay small whatever the batch, and one launch covers any tensor size.  Base and size are
+    // workgroup-uniform state of the DMA cursor (scalar registers); the descriptor is assembled where it is used.
+    unsigned long long a_ptr = (unsigned long long)p.in, a2_ptr = FOLD ? (unsigned long long)p.in2 : 0ull;
+    unsigned a_nrec = 0u, a2_nrec = 0u;
     const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.wgt, p.wgt_bytes);
-    const __amdgpu_buffer_rsrc_t a2_rsrc = make_rsrc(FOLD ? p.in2 : nullptr, FOLD ? p.in2_bytes : 0u);
 
     auto tile_origin = [&](int v, int& m0, int& n0) {
         // XCD-aware bijective remap: ids v, v+8, ... run on one XCD; give each XCD a contiguous range of tiles
@@ -214,6 +219,18 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
         tile_origin(iv, m0, n0);
         i_m0 = m0;
         i_n0 = n0;
+        const unsigned b0 = FOLD ? 0u : (unsigned)m0 / (unsigned)HgWg;            // first image of the tile
+        {
+            const unsigned long long pix0 = FOLD ? (unsigned long long)m0 : (unsigned long long)b0 * (unsigned)(p.Hi * p.Wi);
+            const unsigned long long off0 = pix0 * (unsigned)p.pix_stride * 2ull, left = p.in_bytes - off0;
+            a_ptr = (unsigned long long)p.in + off0;
+            a_nrec = left < 0x7fff0000ull ? (unsigned)left : 0x7fff0000u;           // (PDT_OOB_OFFSET stays beyond it)
+            if (FOLD) {
+                const unsigned long long off2 = pix0 * (unsigned)p.pix_stride2 * 2ull, left2 = p.in2_bytes - off2;
+                a2_ptr = (unsigned long long)p.in2 + off2;
+                a2_nrec = left2 < 0x7fff0000ull ? (unsigned)left2 : 0x7fff0000u;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < A_DMA; ++j) {
             const int row = (wave * A_DMA + j) * RPI + d_row;
@@ -221,13 +238,13 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
             m = m < p.M ? m : p.M - 1;                       // rows past the end are computed and thrown away
             if (FOLD) {
                 // (launcher: one tap at offset 0, IS == 1 and the grid is the input image: GEMM row m is input pixel m)
-                a_base[j] = m;
+                a_base[j] = m - m0;
                 a_y[j] = 0;
                 a_x[j] = 0;
             } else {
                 unsigned b = (unsigned)m / (unsigned)HgWg, rem = (unsigned)m - b * (unsigned)HgWg;
                 unsigned y = rem / (unsigned)p.Wg, x = rem - y * (unsigned)p.Wg;
-                a_base[j] = (int)b * p.Hi * p.Wi;
+                a_base[j] = (int)(b - b0) * p.Hi * p.Wi;
                 a_y[j] = (int)y * p.IS;
                 a_x[j] = (int)x * p.IS;
             }
@@ -248,6 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
         const bool second = FOLD && it == p.T;                // workgroup-uniform: the phase of the second operand
         unsigned wofs;
         if (!second) {
+            const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(reinterpret_cast<const void*>(a_ptr), a_nrec);
             const int tap = p.taps[__builtin_amdgcn_readfirstlane(it)];
             const int oy = (int)(signed char)(tap & 0xff), ox = (int)(signed char)((tap >> 8) & 0xff), wi = (tap >> 16) & 0xffff;
             wofs = (unsigned)(wi * p.Ci + c0) * 2u;
@@ -266,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
             }
         } else {
             wofs = (unsigned)(p.T * p.Ci + c0) * 2u;
+            const __amdgpu_buffer_rsrc_t a2_rsrc = make_rsrc(reinterpret_cast<const void*>(a2_ptr), a2_nrec);
 #pragma unroll
             for (int j = 0; j < A_DMA; ++j)
                 dma16(a2_rsrc, As + (wave * A_DMA + j) * 1024, (unsigned)(a_base[j] * p.pix_stride2 + c0) * 2u + a_sw[j], 0u);
@@ -955,7 +974,6 @@ PDT_API int pdt_conv_dma_ex(const void* in, const void* wgt, void* out, const vo
     }
     if (in2) {
         if (Ci2 < 64 || Ci2 % 64 != 0 || pix_stride2 < Ci2 || pix_stride2 % 8 != 0) return -11;
-        if (M * (long long)pix_stride2 * 2 >= 0x7fff0000LL) return -7;
     }
     if ((relu_out || bits_out) && (!(in2 || bias) || bstat_y)) return -12;   // forward instantiations with a second operand / start values only
     if ((in2 || bias) && stat_acc && !bstat_y) return -12;                   // ... which carry no statistics epilogue
@@ -990,13 +1008,16 @@ PDT_API int pdt_conv_dma_ex(const void* in, const void* wgt, void* out, const vo
 #ifdef PDT_DMA_DIAG
     { const char* e = getenv("PDT_DMA_DIAG"); p.diag = e ? atoi(e) : 0; }
 #endif
-    p.in2_bytes = in2 ? (unsigned)(M * (long long)pix_stride2 * 2) : 0u;
+    p.in2_bytes = in2 ? (unsigned long long)(M * (long long)pix_stride2 * 2) : 0ull;
     {
         long long images = M / ((long long)Hg * Wg);
         long long in_b = images * Hi * Wi * pix_stride * 2, w_b = (long long)N * wrow * 2;
-        // byte offsets are 32-bit; PDT_OOB_OFFSET must stay beyond both tensors
-        if (in_b >= 0x7fff0000LL || w_b >= 0x7fff0000LL) return -7;
-        p.in_bytes = (unsigned)in_b;
+        // 32-bit byte offsets from a per-tile base: what ONE tile reaches (its rows' images, at most 256 rows) and the
+        // weights must stay within a descriptor, and PDT_OOB_OFFSET beyond both
+        long long reach = (256 / ((long long)Hg * Wg) + 2) * Hi * Wi * pix_stride * 2;
+        long long reach2 = 256LL * (pix_stride2 > pix_stride ? pix_stride2 : pix_stride) * 2;
+        if (reach >= 0x7fff0000LL || reach2 >= 0x7fff0000LL || w_b >= 0x7fff0000LL) return -7;
+        p.in_bytes = (unsigned long long)in_b;
         p.wgt_bytes = (unsigned)w_b;
     }
     for (int i = 0; i < T; ++i)

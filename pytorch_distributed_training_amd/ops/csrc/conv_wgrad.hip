@@ -55,7 +55,7 @@ struct WgradParams {
     float* ws;                         // deterministic mode: [splitk][slab] partial outputs, else NULL
     long long slab;                    // floats per slab (= N * wrow)
     long long M;
-    unsigned in_bytes, dy_bytes;       // tensor sizes for the buffer descriptors
+    unsigned long long in_bytes, dy_bytes;   // tensor sizes; descriptors are based at the workgroup's slice (see slice_rsrc)
     int Hi, Wi, pix_stride, Ci;
     int Hg, Wg, IS;
     int N, ldy, wrow, T;
@@ -76,6 +76,14 @@ __host__ __device__ __forceinline__ void unpack_tap(int w, int& oy, int& ox, int
     oy = (int)(signed char)(w & 0xff);
     ox = (int)(signed char)((w >> 8) & 0xff);
     widx = (w >> 16) & 0xffff;
+}
+
+// Descriptor for ``bytes`` of a tensor from byte ``off`` on: offsets inside a slice are 32-bit, the slice's start is
+// not -- one launch covers tensors of any size (the launcher keeps what one slice reaches below 2 GiB).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slice_rsrc(const void* base, unsigned long long off,
+                                                             unsigned long long total) {
+    const unsigned long long left = total > off ? total - off : 0ull;
+    return make_rsrc(static_cast<const unsigned char*>(base) + off, left < 0x7fff0000ull ? (unsigned)left : 0x7fff0000u);
 }
 
 __device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char* base0, const unsigned char* base1) {
@@ -167,10 +175,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     const bool a_col_ok = co0 + a_cv * 8 < p.N;          // N is checked at 8-granularity (ldy padded)
     const bool b_col_ok = ci0 + b_cv * 8 < p.Ci;
 
-    // The dY descriptor ends at this slice's last row: rows past the slice read zeros through the range check.
-    const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(p.dy, (unsigned)((unsigned long long)r_end * (unsigned)p.ldy * 2u));
+    // The descriptors start at this slice's first row (gathered operand: first image) and the dY one ends at its last
+    // row: rows past the slice read zeros through the range check.
+    const unsigned b_first = LINEAR ? 0u : r_begin / (unsigned)(p.Hg * p.Wg);
+    const __amdgpu_buffer_rsrc_t dy_rsrc = slice_rsrc(p.dy, (unsigned long long)r_begin * (unsigned)p.ldy * 2ull,
+                                                      (unsigned long long)r_end * (unsigned)p.ldy * 2ull);
     const __amdgpu_buffer_rsrc_t in_rsrc =
-        make_rsrc(p.in, LINEAR ? (unsigned)((unsigned long long)r_end * (unsigned)p.pix_stride * 2u) : p.in_bytes);
+        LINEAR ? slice_rsrc(p.in, (unsigned long long)r_begin * (unsigned)p.pix_stride * 2ull,
+                            (unsigned long long)r_end * (unsigned)p.pix_stride * 2ull)
+               : slice_rsrc(p.in, (unsigned long long)b_first * (unsigned)(p.Hi * p.Wi) * (unsigned)p.pix_stride * 2ull, p.in_bytes);
     // two register sets: the loads of K step s+2 are issued before step s is multiplied, so a load has two steps of
     // MFMA work (not one) to come back before its ds_write needs it
     bf16x8 a_reg0[A_IT], b_reg0[B_IT], a_reg1[A_IT], b_reg1[B_IT];
@@ -178,14 +191,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     RowPos pos[B_IT];
 #pragma unroll
     for (int j = 0; j < A_IT; ++j) {
-        unsigned m = r_begin + a_row + j * A_RPP;
+        unsigned m = a_row + j * A_RPP;                    // relative to the slice
         a_off[j] = a_col_ok ? (m * (unsigned)p.ldy + co0 + a_cv * 8) * 2u : PDT_OOB_OFFSET;
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
-        unsigned m = r_begin + b_row + j * B_RPP;
+        unsigned m = b_row + j * B_RPP;
         if (LINEAR) b_off[j] = b_col_ok ? (m * (unsigned)p.pix_stride + ci0 + b_cv * 8) * 2u : PDT_OOB_OFFSET;
-        else pos[j] = row_pos(m, p.Hg * p.Wg, p.Wg);
+        else {
+            pos[j] = row_pos(r_begin + m, p.Hg * p.Wg, p.Wg);
+            pos[j].b -= (int)b_first;
+        }
     }
     const unsigned a_step = a_col_ok ? (unsigned)(BKP * p.ldy * 2) : 0u;
     const unsigned b_step = b_col_ok ? (unsigned)(BKP * p.pix_stride * 2) : 0u;
@@ -349,9 +365,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
     const int nk = r_begin < r_end ? (int)((r_end - r_begin + BKP - 1) / BKP) : 0;
     if (nk == 0) return;
 
-    const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(p.dy, (unsigned)((unsigned long long)r_end * (unsigned)p.ldy * 2u));
+    const unsigned b_first = LINEAR ? 0u : r_begin / (unsigned)(p.Hg * p.Wg);
+    const __amdgpu_buffer_rsrc_t dy_rsrc = slice_rsrc(p.dy, (unsigned long long)r_begin * (unsigned)p.ldy * 2ull,
+                                                      (unsigned long long)r_end * (unsigned)p.ldy * 2ull);
     const __amdgpu_buffer_rsrc_t in_rsrc =
-        make_rsrc(p.in, LINEAR ? (unsigned)((unsigned long long)r_end * (unsigned)p.pix_stride * 2u) : p.in_bytes);
+        LINEAR ? slice_rsrc(p.in, (unsigned long long)r_begin * (unsigned)p.pix_stride * 2ull,
+                            (unsigned long long)r_end * (unsigned)p.pix_stride * 2ull)
+               : slice_rsrc(p.in, (unsigned long long)b_first * (unsigned)(p.Hi * p.Wi) * (unsigned)p.pix_stride * 2ull, p.in_bytes);
 
     // DMA instruction j of this wave fills rows (j * 4 + wave) * 4 + (lane >> 4) of both tiles
     const int lrow = lane >> 4, lchunk = lane & 15;
@@ -362,14 +382,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
     for (int j = 0; j < IT; ++j) {
         const int row = (j * 4 + wave) * 4 + lrow;
         const int src_chunk = lchunk ^ ((row & 7) * 2);
-        const unsigned m = r_begin + row;
+        const unsigned m = (unsigned)row;                  // relative to the slice
         const bool a_ok = co0 + src_chunk * 8 < p.N;
         const bool b_ok = ci0 + src_chunk * 8 < p.Ci;
         a_off[j] = a_ok ? (m * (unsigned)p.ldy + co0 + src_chunk * 8) * 2u : PDT_OOB_OFFSET;
         if (LINEAR) {
             b_off[j] = b_ok ? (m * (unsigned)p.pix_stride + ci0 + src_chunk * 8) * 2u : PDT_OOB_OFFSET;
         } else {
-            pos[j] = row_pos(m, p.Hg * p.Wg, p.Wg);
+            pos[j] = row_pos(r_begin + m, p.Hg * p.Wg, p.Wg);
+            pos[j].b -= (int)b_first;
             b_colb[j] = b_ok ? (unsigned)(ci0 + src_chunk * 8) * 2u : PDT_OOB_OFFSET;
         }
     }
@@ -525,18 +546,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(const WgradParams p)
     const bool a_col_ok = co0 + a_cv * 8 < p.N;
     const bool b_col_ok = b_cv * 8 < p.Ci;
 
-    const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(p.dy, (unsigned)((unsigned long long)r_end * (unsigned)p.ldy * 2u));
-    const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(p.in, p.in_bytes);
+    const unsigned b_first = r_begin / (unsigned)(p.Hg * p.Wg);
+    const __amdgpu_buffer_rsrc_t dy_rsrc = slice_rsrc(p.dy, (unsigned long long)r_begin * (unsigned)p.ldy * 2ull,
+                                                      (unsigned long long)r_end * (unsigned)p.ldy * 2ull);
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        slice_rsrc(p.in, (unsigned long long)b_first * (unsigned)(p.Hi * p.Wi) * (unsigned)p.pix_stride * 2ull, p.in_bytes);
     bf16x8 a_reg[A_IT], b_reg[TAPS][B_IT];
     unsigned a_off[A_IT];
     RowPos pos[B_IT];
 #pragma unroll
     for (int j = 0; j < A_IT; ++j) {
-        unsigned m = r_begin + a_row + j * A_RPP;
+        unsigned m = a_row + j * A_RPP;                    // relative to the slice
         a_off[j] = a_col_ok ? (m * (unsigned)p.ldy + co0 + a_cv * 8) * 2u : PDT_OOB_OFFSET;
     }
 #pragma unroll
-    for (int j = 0; j < B_IT; ++j) pos[j] = row_pos(r_begin + b_row + j * B_RPP, p.Hg * p.Wg, p.Wg);
+    for (int j = 0; j < B_IT; ++j) {
+        pos[j] = row_pos(r_begin + b_row + j * B_RPP, p.Hg * p.Wg, p.Wg);
+        pos[j].b -= (int)b_first;
+    }
     const unsigned a_step = a_col_ok ? (unsigned)(BKP * p.ldy * 2) : 0u;
     unsigned m_b = r_begin + b_row;
     auto load_tiles = [&]() {
@@ -714,17 +741,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_row3_kernel(const WgradParams p)
 
     // Whole tensors behind the descriptors: a slice is a whole number of K steps, positions past the last image are
     // past the tensors' ends and read zeros.
-    const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(p.dy, p.dy_bytes);
-    const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(p.in, p.in_bytes);
+    // ... and the descriptors start at the slice's first image row (the gathered operand's: one row earlier, for oy = -1),
+    // so the 32-bit offsets below are relative to the slice whatever the tensors' sizes
+    const unsigned row0 = r_begin >> lp;                   // first image row (b * H + y) of the slice
+    const unsigned xrow0 = row0 > 0u ? row0 - 1u : 0u;
+    const __amdgpu_buffer_rsrc_t dy_rsrc = slice_rsrc(p.dy, (unsigned long long)row0 * (unsigned)W * (unsigned)p.ldy * 2ull, p.dy_bytes);
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        slice_rsrc(p.in, (unsigned long long)xrow0 * (unsigned)W * (unsigned)p.pix_stride * 2ull, p.in_bytes);
     bf16x8 a_reg0[A_IT], b_reg0[B_IT], a_reg1[A_IT], b_reg1[B_IT];
     unsigned a_off[A_IT], b_off[B_IT];
     int b_y[B_IT];
     bool b_ok[B_IT];
-    const unsigned row0 = r_begin >> lp;                   // first image row (b * H + y) of the slice
 #pragma unroll
     for (int j = 0; j < A_IT; ++j) {
         const int pos = a_row + j * A_RPP, q = pos & (P - 1);
-        const unsigned rr = row0 + (unsigned)(pos >> lp);
+        const unsigned rr = (unsigned)(pos >> lp);         // relative to row0
         const bool ok = a_col_ok && q >= 1 && q <= W;
         a_off[j] = ok ? ((rr * (unsigned)W + (unsigned)(q - 1)) * (unsigned)p.ldy + co0 + a_cv * 8) * 2u : PDT_OOB_OFFSET;
     }
@@ -734,8 +765,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_row3_kernel(const WgradParams p)
         const unsigned rr = row0 + (unsigned)(pos >> lp);
         b_ok[j] = b_col_ok && q >= 1 && q <= W;
         b_y[j] = (int)(rr % (unsigned)H);
-        // (rr + oy) * W + q - 1 may be "negative" for the very first row: refused by the row test below
-        b_off[j] = (((rr + (unsigned)oy) * (unsigned)W + (unsigned)(q - 1)) * (unsigned)p.pix_stride + ci0 + b_cv * 8) * 2u;
+        // (rr - xrow0 + oy) * W + q - 1 may be "negative" for the tensor's very first row: refused by the row test below
+        b_off[j] = (((rr - xrow0 + (unsigned)oy) * (unsigned)W + (unsigned)(q - 1)) * (unsigned)p.pix_stride + ci0 + b_cv * 8) * 2u;
     }
     const int rows_step = BKP >> lp;                       // image rows per K step
     const unsigned a_step = (unsigned)(rows_step * W * p.ldy * 2);
@@ -878,6 +909,30 @@ static int launch_fold(const WgradParams& p, hipStream_t s) {
     return pdt_launch_status();
 }
 
+// Rows a slice may have so that what it reaches of either operand stays inside one descriptor (the kernels address a
+// slice with 32-bit offsets from its first row / image): 1.5 GiB over the larger per-row footprint, less two images of
+// slack for the gathered operand's image granularity.  < 2 K steps: the geometry cannot be served (-7).
+static long long slice_rows_limit(const WgradParams& p, long long rows_per_image) {
+    const long long dy_row = (long long)p.ldy * 2;
+    const long long in_row = ((long long)p.Hi * p.Wi * p.pix_stride * 2 + rows_per_image - 1) / rows_per_image;
+    return 0x60000000LL / (dy_row > in_row ? dy_row : in_row) - 2 * rows_per_image;
+}
+
+// split / rows_per_split from a wanted split: whole K steps per slice, every slice within reach
+static int size_slices(WgradParams& p, long long split, long long rows_per_image, long long ws_slabs) {
+    const long long lim = slice_rows_limit(p, rows_per_image);
+    if (lim < 2 * BKP) return -7;
+    if (split < 1) split = 1;
+    long long rps = (p.M + split - 1) / split;
+    if (rps > lim) rps = lim;
+    rps = (rps + BKP - 1) / BKP * BKP;
+    split = (p.M + rps - 1) / rps;
+    if (p.ws && split > ws_slabs) return -8;
+    p.splitk = (int)split;
+    p.rows_per_split = rps;
+    return 0;
+}
+
 template <int BMO, int BNC, int WM, int WN, int TAPS>
 static int launch_wgrad_taps(WgradParams& p, hipStream_t s, int target_blocks, long long ws_slabs) {
     if (p.T % TAPS != 0 || p.Ci > BNC) return -6;
@@ -886,13 +941,8 @@ static int launch_wgrad_taps(WgradParams& p, hipStream_t s, int target_blocks, l
     long long split = (target_blocks + n_ct - 1) / n_ct;
     if (split > max_split) split = max_split;
     if (p.ws && split > ws_slabs) split = ws_slabs;
-    if (split < 1) split = 1;
-    long long rps = (p.M + split - 1) / split;
-    rps = (rps + BKP - 1) / BKP * BKP;
-    split = (p.M + rps - 1) / rps;
-    p.splitk = (int)split;
-    p.rows_per_split = rps;
-    long long nwg = (long long)n_ct * split;
+    if (int rc = size_slices(p, split, (long long)p.Hg * p.Wg, ws_slabs)) return rc;
+    long long nwg = (long long)n_ct * p.splitk;
     if (nwg > 0x7fffffffLL) return -2;
     hipLaunchKernelGGL((wgrad_taps_kernel<BMO, BNC, WM, WN, TAPS>), dim3((unsigned)nwg), dim3(256), 0, s, p);
     return launch_fold(p, s);
@@ -915,13 +965,8 @@ static int launch_wgrad(WgradParams& p, hipStream_t s, int target_blocks, long l
     if (budget_split < 1) budget_split = 1;
     if (split > budget_split) split = budget_split;
     if (p.ws && split > ws_slabs) split = ws_slabs;
-    if (split < 1) split = 1;
-    long long rps = (p.M + split - 1) / split;
-    rps = (rps + BKP - 1) / BKP * BKP;
-    split = (p.M + rps - 1) / rps;
-    p.splitk = (int)split;
-    p.rows_per_split = rps;
-    long long nwg = tiles * split;
+    if (int rc = size_slices(p, split, (long long)p.Hg * p.Wg, ws_slabs)) return rc;
+    long long nwg = tiles * p.splitk;
     if (nwg > 0x7fffffffLL) return -2;
     // 1x1 / stride 1 / no padding over a dense input: GEMM row m is input pixel m
     const bool linear = p.T == 1 && (p.taps[0] & 0xffff) == 0 && p.IS == 1 && p.Hg == p.Hi && p.Wg == p.Wi;
@@ -978,13 +1023,9 @@ static int launch_wgrad_row3(WgradParams& p, hipStream_t s, int target_blocks, l
     if (budget_split < 1) budget_split = 1;
     if (split > budget_split) split = budget_split;
     if (p.ws && split > ws_slabs) split = ws_slabs;
-    if (split < 1) split = 1;
-    long long rps = (p.M + split - 1) / split;
-    rps = (rps + BKP - 1) / BKP * BKP;
-    split = (p.M + rps - 1) / rps;
-    p.splitk = (int)split;
-    p.rows_per_split = rps;
-    long long nwg = tiles * split;
+    // (a "row" of this kernel is a position: P per image row of W pixels)
+    if (int rc = size_slices(p, split, (long long)p.Hg << lp, ws_slabs)) return rc;
+    long long nwg = tiles * p.splitk;
     if (nwg > 0x7fffffffLL) return -2;
     hipLaunchKernelGGL((wgrad_row3_kernel<BMO, BNC, WM, WN>), dim3((unsigned)nwg), dim3(256), 0, s, p);
     return launch_fold(p, s);
@@ -1018,9 +1059,8 @@ PDT_API int pdt_conv_wgrad_ex(const void* dy, const void* in, float* dw, long lo
     {
         long long images = M / ((long long)Hg * Wg);
         long long in_b = images * Hi * Wi * pix_stride * 2, dy_b = M * (long long)ldy * 2;
-        if (in_b >= (long long)PDT_OOB_OFFSET || dy_b >= (long long)PDT_OOB_OFFSET) return -7;
-        p.in_bytes = (unsigned)in_b;
-        p.dy_bytes = (unsigned)dy_b;
+        p.in_bytes = (unsigned long long)in_b;
+        p.dy_bytes = (unsigned long long)dy_b;
     }
     p.Hg = Hg; p.Wg = Wg; p.IS = IS; p.N = N; p.ldy = ldy; p.wrow = wrow; p.T = T;
     {

@@ -303,11 +303,12 @@ def _stem_taps() -> _Taps:
     return _tap_cache[key]
 
 
-# The conv kernels address their gathered operand through a buffer descriptor with 32-bit byte
-# offsets (out-of-range taps read zeros for free), so one launch sees at most 2 GB of it; larger
-# batches (per-GPU batch > ~1200 on ResNet-50's first stage) go out as several launches over
-# batch ranges -- rows of different images are independent, statistics and weight gradients
-# accumulate across the launches.
+# The conv kernels address their operands through buffer descriptors with 32-bit byte offsets (out-of-range taps read
+# zeros for free).  The streaming kernels (conv_dma.hip, conv_wgrad.hip) base the descriptor at the tile / slice they
+# are working on, so ONE launch covers tensors of any size.  The register-staged fallback kernel (conv_igemm.hip: stem
+# without LDS-DMA, classifier, odd channel counts) keeps a whole-tensor descriptor and therefore sees at most 2 GB of
+# its gathered operand: beyond that its launches go out over batch ranges (rows of different images are independent,
+# statistics accumulate across the launches).
 MAX_OPERAND_BYTES = 0x70000000
 
 
@@ -326,7 +327,10 @@ def _part(t, b0: int, b1: int):
 def _igemm(inp, wgt, out, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0, ox0, N, ldo, wrow, taps: _Taps,
            addend=None, mask=None, bias=None, stat_acc=None, stat_shift=None, tile: int = 0, bstat=None,
            mask_bits: bool = False, addend_half: bool = False, sums_only: bool = False) -> None:
-    parts = _batch_parts(inp.shape[0], inp.numel() * inp.element_size())
+    dma = (_USE_CONV_DMA and tile <= 0 and bias is None and ldo == N and N % 64 == 0 and Ci % 64 == 0 and taps.T >= 1
+           and pix_stride % 8 == 0 and (mask is None or mask_bits) and (_DMA_TAPS or taps.T == 1)
+           and N * wrow * 2 < 0x7fff0000)
+    parts = None if dma else _batch_parts(inp.shape[0], inp.numel() * inp.element_size())
     if parts is not None:
         B = inp.shape[0]
         if out.shape[0] != B or M % B:
@@ -338,9 +342,7 @@ def _igemm(inp, wgt, out, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0
                    stat_acc=stat_acc, stat_shift=stat_shift, tile=tile, bstat=sub, mask_bits=mask_bits,
                    addend_half=addend_half, sums_only=sums_only)
         return
-    if (_USE_CONV_DMA and tile <= 0 and bias is None and ldo == N and N % 64 == 0 and Ci % 64 == 0 and taps.T >= 1
-            and pix_stride % 8 == 0 and (mask is None or mask_bits) and (_DMA_TAPS or taps.T == 1)
-            and inp.numel() * 2 < 0x7fff0000 and N * wrow * 2 < 0x7fff0000):
+    if dma:
         acc, by, bmean, bscale, bshift = bstat if bstat is not None else (stat_acc, None, None, None, None)
         rc = _lib.pdt_conv_dma(_p(inp), _p(wgt), _p(out), _p(addend), int(addend_half), _p(mask), _p(acc), _p(stat_shift),
                                _p(by), _p(bmean), _p(bscale), _p(bshift), M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS,
@@ -363,21 +365,23 @@ def _igemm(inp, wgt, out, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, Ho, Wo, OS, oy0
 
 
 def _wgrad(dy, inp, dw, M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow, taps: _Taps, tile: int = 0,
-           target_blocks: int = 0, atomic_budget_mb: int = 0, row_scale=None) -> None:
-    parts = _batch_parts(inp.shape[0], max(inp.numel(), dy.numel()) * 2)
-    if parts is not None:
-        B = inp.shape[0]
-        if dy.shape[0] != B or M % B:
-            raise ValueError("conv_wgrad: cannot split this launch over the batch")
-        for b0, b1 in parts:
-            _wgrad(dy[b0:b1], inp[b0:b1], dw, (M // B) * (b1 - b0), Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow,
-                   taps, tile=tile, target_blocks=target_blocks, atomic_budget_mb=atomic_budget_mb, row_scale=row_scale)
-        return
+           target_blocks: int = 0, atomic_budget_mb: int = 0, row_scale=None, part_ok: bool = True) -> None:
     stream = _stream()
     ws, ws_bytes = _wgrad_workspace(dw.device, stream)
     rc = _lib.pdt_conv_wgrad_ex(_p(dy), _p(inp), _p(dw), M, Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow, taps.T,
                                 taps.offy, taps.offx, taps.widx, tile, target_blocks, atomic_budget_mb, ws, ws_bytes,
                                 _p(row_scale), stream)
+    if rc == -8 and part_ok:
+        # deterministic mode: more slices than the workspace has slabs are needed to keep every slice within a
+        # descriptor's reach -- the one case that still goes out over batch ranges
+        parts = _batch_parts(inp.shape[0], max(inp.numel(), dy.numel()) * 2)
+        B = inp.shape[0]
+        if parts is not None and dy.shape[0] == B and M % B == 0:
+            for b0, b1 in parts:
+                _wgrad(dy[b0:b1], inp[b0:b1], dw, (M // B) * (b1 - b0), Hi, Wi, pix_stride, Ci, Hg, Wg, IS, N, ldy, wrow,
+                       taps, tile=tile, target_blocks=target_blocks, atomic_budget_mb=atomic_budget_mb,
+                       row_scale=row_scale, part_ok=False)
+            return
     _check(rc, "pdt_conv_wgrad")
 
 
@@ -971,8 +975,7 @@ def conv_dgrad_folded(g: torch.Tensor, a_in: torch.Tensor, fold: BnFold, bwd_sta
             bscale = bshift = None
         acc = _accumulator(g.device, C, "bwd")
     taps = _one_tap()
-    parts = _batch_parts(B, g.numel() * 2) or [(0, B)]
-    for b0, b1 in parts:
+    for b0, b1 in [(0, B)]:           # (one launch whatever the size: the kernel rebases its descriptors per tile)
         M = (b1 - b0) * H * W
         rc = _lib.pdt_conv_dma_ex(_p(g[b0:b1]), _p(fold.wfold), _p(dx[b0:b1]), None, 0, None, _p(acc), None,
                                   _p(by[b0:b1]) if by is not None else None, _p(bmean), _p(bscale), _p(bshift), M, H, W, N,
@@ -1065,8 +1068,7 @@ def conv_fprop_fused_tail(a: torch.Tensor, wf: torch.Tensor, shift: torch.Tensor
     if bits_out is not None:
         _check_bits(bits_out, (B, H, W, N), "conv_fprop_fused_tail bits_out")
     taps = _one_tap()
-    parts = _batch_parts(B, max(y.numel(), a.numel()) * 2) or [(0, B)]
-    for b0, b1 in parts:
+    for b0, b1 in [(0, B)]:           # (one launch whatever the size: the kernel rebases its descriptors per tile)
         M = (b1 - b0) * H * W
         rc = _lib.pdt_conv_dma_ex(_p(a[b0:b1]), _p(wf), _p(y[b0:b1]), _p(_part(addend, b0, b1)), 0, None, None, None, None,
                                   None, None, None, M, H, W, C, C, H, W, 1, H, W, 1, 0, 0, N, C + C2, 1, taps.offy,

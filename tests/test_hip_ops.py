@@ -91,8 +91,8 @@ def test_conv_tiles(hip, device, tile):
 
 @pytest.mark.parametrize("k,stride,pad", [(1, 1, 0), (3, 1, 1), (3, 2, 1)])
 def test_conv_launches_split_over_the_batch(hip, device, monkeypatch, k, stride, pad):
-    """Operands beyond the 2 GB buffer-descriptor window go out as several launches over batch
-    ranges (threshold lowered here): same outputs, statistics and weight gradients."""
+    """Register-staged kernel: operands beyond the 2 GB buffer-descriptor window go out as several launches over
+    batch ranges (threshold lowered here): same outputs, statistics and weight gradients."""
     torch.manual_seed(k + stride)
     B, H, Ci, Co = 7, 12, 64, 128
     x = rnd(B, H, H, Ci, device=device)
@@ -115,6 +115,8 @@ def test_conv_launches_split_over_the_batch(hip, device, monkeypatch, k, stride,
         hip.conv_wgrad(x, dy, k, k, stride, pad, dw)
         return y, mom, dx, sums, dw
 
+    # (only the register-staged kernel splits: the streaming kernels rebase their descriptors and take any size)
+    monkeypatch.setattr(hip, "_USE_CONV_DMA", False)
     torch.manual_seed(1)
     whole = run()
     monkeypatch.setattr(hip, "MAX_OPERAND_BYTES", x[:2].numel() * 2)       # -> 4 launches of <= 2 images
@@ -125,6 +127,52 @@ def test_conv_launches_split_over_the_batch(hip, device, monkeypatch, k, stride,
     assert torch.allclose(whole[1], split[1], rtol=1e-4, atol=1e-5)
     assert torch.allclose(whole[3], split[3], rtol=1e-3, atol=1e-2)
     assert rel_err(split[4], whole[4]) < 1e-4
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_tensors_beyond_two_gigabytes_in_one_launch(hip, device, k):
+    """2.25 GB activations (1400 images of 112 x 112 x 64) through ONE launch each of the streaming kernels -- forward,
+    data gradient with its fused epilogue, weight gradient, and the two-operand block tail -- against the same ops on
+    two halves that each fit a descriptor.  Outputs are equal bit for bit (a row's value does not depend on the launch
+    it is computed in), sums and weight gradients to accumulation order."""
+    B, H, C = 1400, 112, 64
+    pad = k // 2
+    g = torch.Generator(device=device).manual_seed(k)
+    x = (torch.randn(B, H, H, C, device=device, generator=g) * 0.5).to(torch.bfloat16)
+    assert x.numel() * 2 > 2 ** 31
+    w = (torch.randn(C, k, k, C, device=device, generator=g) * (2.0 / (k * k * C)) ** 0.5).to(torch.bfloat16)
+    wt = torch.empty(C, k, k, C, dtype=torch.bfloat16, device=device)
+    hip.transpose_weights(w, wt)
+    shift = torch.zeros(C, device=device)
+    halves = [(0, B // 2), (B // 2, B)]
+
+    y, mom = hip.conv_fprop(x, w, k, k, 1, pad, shift)
+    parts = [hip.conv_fprop(x[a:b], w, k, k, 1, pad, shift) for a, b in halves]
+    for (a, b), (yp, _) in zip(halves, parts):
+        assert torch.equal(y[a:b], yp)
+    assert torch.allclose(mom, 0.5 * (parts[0][1] + parts[1][1]), rtol=1e-3, atol=1e-4)
+
+    bits = hip.new_relu_bits(x)
+    ref._pack_bits(x, bits)
+    dx = hip.conv_dgrad(y, w, wt, tuple(x.shape), k, k, 1, pad, addend=x, relu_bits=bits)
+    for a, b in halves:
+        part = hip.conv_dgrad(y[a:b], w, wt, (b - a, H, H, C), k, k, 1, pad, addend=x[a:b], relu_bits=bits[a:b])
+        assert torch.equal(dx[a:b], part)
+    del dx
+
+    dw = torch.zeros(C, k, k, C, dtype=torch.float32, device=device)
+    hip.conv_wgrad(x, y, k, k, 1, pad, dw)
+    dw2 = torch.zeros_like(dw)
+    for a, b in halves:
+        hip.conv_wgrad(x[a:b], y[a:b], k, k, 1, pad, dw2)
+    assert rel_err(dw, dw2) < 1e-4
+
+    if k == 1:                                           # second operand: both tensors beyond 2 GB
+        wf = (torch.randn(C, 2 * C, device=device, generator=g) * 0.1).to(torch.bfloat16)
+        sh = torch.randn(C, device=device, generator=g)
+        out = hip.conv_fprop_fused_tail(x, wf, sh, in2=y)
+        for a, b in halves:
+            assert torch.equal(out[a:b], hip.conv_fprop_fused_tail(x[a:b], wf, sh, in2=y[a:b]))
 
 
 @pytest.mark.parametrize("tile", [1, 2, 4, 8, 9, 10, 11])
