@@ -83,9 +83,32 @@ def get(role: str, device: torch.device, priority: Optional[int] = None) -> "tor
         if count(device) >= BUDGET:
             raise RuntimeError(f"stream budget exceeded: {sorted(in_use(device))} are in use on cuda:{dev}, no room for "
                                f"{role!r} (at most {BUDGET} streams per rank, RCCL's included)")
-        s = torch.cuda.Stream(device=device, **({"priority": int(priority)} if priority is not None else {}))
+        s = _masked_stream(role, device) or \
+            torch.cuda.Stream(device=device, **({"priority": int(priority)} if priority is not None else {}))
     _streams[(dev, slot)] = s
     return s
+
+
+_keep_alive = []
+
+
+def _masked_stream(role: str, device: torch.device):
+    """Measurement aid: ``PDT_CU_MASK_<ROLE>=<hex words, comma separated, least significant first>`` creates the role's
+    stream on a subset of the compute units (``hipExtStreamCreateWithCUMask``).  None when not asked for."""
+    spec = os.environ.get(f"PDT_CU_MASK_{role.upper()}")
+    if not spec:
+        return None
+    import ctypes
+    words = [int(w, 16) for w in spec.split(",")]
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    hip = ctypes.CDLL("libamdhip64.so")
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(len(words)), arr)
+    if rc != 0:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed with status {rc}")
+    _keep_alive.append((hip, arr))
+    return torch.cuda.ExternalStream(handle.value, device=device)
 
 
 def reset() -> None:
