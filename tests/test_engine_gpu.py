@@ -131,3 +131,31 @@ def test_every_model_family_trains_through_the_engine(device, name):
     spec = get_spec(name, 100)
     assert set(sd) == set(spec.state_dict_schema())
     assert sum(v.numel() for k, v in sd.items() if k in spec.parameter_keys()) == spec.num_parameters()
+
+
+def test_reference_ops_on_the_gpu_update_after_backward(device):
+    """The per-bucket optimizer runs a bucket's update while backward is still going; that is sound only for a backend
+    whose data-gradient kernels do not read the forward weights (the HIP kernels read transposed copies).  The reference
+    ops DO read them, so on a GPU (where the hooks run inside backward) the engine must keep the whole-model update
+    after backward for them -- and then trains exactly like the same ops on the CPU, where hooks are deferred."""
+    from pytorch_distributed_training_amd.config import validate_cfg
+    from pytorch_distributed_training_amd.engine.engines import build_engine
+    cfg = validate_cfg({
+        "dataset": {"name": "synthetic", "n_classes": 10, "image_size": 32},
+        "training": {"optimizer": {"name": "SGD", "lr": 0.05, "weight_decay": 1e-4, "momentum": 0.9},
+                     "lr_schedule": {"name": "constant"}, "train_iters": 4, "batch_size": 8, "per_gpu_batch_size": 8,
+                     "sync_bn": False, "precision": "fp32", "optimizer_in_backward": True},
+        "model": {"name": "ResNet18"}})
+    g = torch.Generator().manual_seed(3)
+    img, label = torch.randn(8, 3, 32, 32, generator=g), torch.randint(0, 10, (8,), generator=g)
+    engines = {}
+    for dev in (device, torch.device("cpu")):
+        torch.manual_seed(0)
+        eng = build_engine(cfg, dev, ops_backend="ref")
+        losses = [float(eng.train_step(img.to(dev), label.to(dev))) for _ in range(3)]
+        engines[dev.type] = (eng, losses)
+    gpu, cpu = engines["cuda"], engines["cpu"]
+    assert not gpu[0].model.optimizer_in_backward            # refused on the GPU for this backend
+    assert gpu[1][0] == pytest.approx(cpu[1][0], rel=1e-4)
+    assert gpu[1][2] == pytest.approx(cpu[1][2], rel=2e-2)   # three updates later: same trajectory (fp32, other summation orders)
+    assert torch.allclose(gpu[0].model.params.p.cpu(), cpu[0].model.params.p, rtol=5e-2, atol=5e-3)
