@@ -11,7 +11,11 @@ mkdir -p "$OUT"
 cd "$ROOT"
 export TMPDIR=/tmp
 step() { echo "== $1"; }
+# REGEN_PARTS: which parts to run (default: all); a GPU call is limited to 20 minutes, two calls cover everything
+PARTS="${REGEN_PARTS:-bench family roofline stats resources pmc forced}"
+want() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
 
+if want bench; then
 step "bench JSONs"
 for b in 256 512 1024 1536; do
   timeout -k 10 280 python bench.py --batch $b --steps 40 --warmup 10 > "$OUT/bench_${SUF}_native_b$b.json" 2> "$OUT/bench_b$b.err" || exit 1
@@ -19,13 +23,19 @@ for b in 256 512 1024 1536; do
 done
 timeout -k 10 280 python bench.py --steps 300 --warmup 10 > "$OUT/bench_${SUF}_native_default_300steps.json" 2> "$OUT/bench_300.err" || exit 1
 
+fi
+if want family; then
 step "model families"
 bash bench/model_family.sh "$OUT/model_family_throughput_$SUF.txt" 1024 || exit 1
 
+fi
+if want roofline; then
 step "roofline (batch 1024)"
 bash bench/roofline.sh "$OUT/roofline_$SUF.txt" 1024 > "$OUT/roofline_head.txt" 2>&1 || { tail -5 "$OUT/roofline_head.txt"; exit 1; }
 head -34 "$OUT/roofline_$SUF.txt"
 
+fi
+if want stats; then
 step "kernel statistics (rocprofv3 --kernel-trace --stats, batch 1024)"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_kernels" -- python3 bench.py --batch 1024 --steps 10 --warmup 5 > "$OUT/prof_kernels.log" 2>&1 || { tail -5 "$OUT/prof_kernels.log"; exit 1; }
 f=$(find "$OUT/prof_kernels" -name '*kernel_stats.csv' | head -1)
@@ -33,11 +43,14 @@ cp "$f" "$OUT/kernel_stats_${SUF}_resnet50_b1024.csv"
 rm -rf "$OUT/prof_kernels"
 head -12 "$OUT/kernel_stats_${SUF}_resnet50_b1024.csv"
 
+fi
+if want resources; then
 step "kernel resources (compiler remarks of this build)"
 python - "$OUT/kernel_resources_$SUF.txt" <<'PY' || exit 1
 import json, sys
 from pytorch_distributed_training_amd.ops import build
-res = json.load(open(build.RESOURCES))
+per_file = json.load(open(build.RESOURCES))
+res = {k: v for kernels in per_file.values() for k, v in kernels.items()}
 names = sorted(res)
 pretty = build.demangle(names)
 with open(sys.argv[1], "w") as f:
@@ -50,6 +63,8 @@ with open(sys.argv[1], "w") as f:
 print(open(sys.argv[1]).read()[:1500])
 PY
 
+fi
+if want pmc; then
 step "hardware counters over the step (three passes, batch 1024)"
 i=0
 for counters in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
@@ -61,6 +76,9 @@ python3 bench/pmc_summary.py "$OUT/pmc" > "$OUT/pmc_step_${SUF}_resnet50_b1024.t
 rm -rf "$OUT/pmc"
 head -40 "$OUT/pmc_step_${SUF}_resnet50_b1024.txt"
 
+fi
+if want forced; then
 step "forced one-rank collectives"
 bash bench/forced_collectives.sh "$OUT/forced_collectives_$SUF.txt" || exit 1
+fi
 echo "regenerated under $OUT"
