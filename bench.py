@@ -253,7 +253,8 @@ def main() -> int:
         return self_launch(args.gpus, sys.argv[1:])          # nothing here has touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rccl_log = None
-    if args.backend == "nccl" and (world > 1 or os.environ.get("PDT_FORCE_COLLECTIVES") == "1"):
+    if args.backend == "nccl" and (world > 1 or os.environ.get("PDT_FORCE_COLLECTIVES") == "1") \
+            and os.environ.get("PDT_RCCL_LOG", "1") != "0":
         rccl_log = rccl_log_setup(bool(args.rccl_tuning_log))
     if world > 1 or args.gpus > 1 or dist_env.env_launch_detected():
         if world != args.gpus:

@@ -97,8 +97,7 @@ class DevicePrefetcher:
         self.transform = transform
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
-        # a stream of its own in a one-rank job; in a multi-rank RCCL job the copy rides on the communication stream (the
-        # rank's fourth stream is RCCL's: see parallel/streams.py)
+        # one of the rank's four streams (parallel/streams.py): an upload queued behind kernels is measurably worse
         self.stream: Optional[torch.cuda.Stream] = streams.get("copy", self.device) if self.cuda else None
         self._next: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._event = None

@@ -17,11 +17,15 @@ Two things keep that safe and cheap:
   stream-to-queue mapping is -- the shared-GPU rehearsal in tests/test_stream_budget_gpu.py runs with TWO queues.
   What WOULD break this is a second host thread submitting GPU work (its packets would interleave differently on each
   rank): loaders, checkpoint writers and loggers in this package never touch the GPU from a side thread.
-* **Budget (performance).**  With at most as many streams as queues no stream is ever serialised behind another one's
-  rendezvous.  A rank owns: compute (the current stream), ``wgrad`` (weight gradients beside the critical path), ``comm``
-  (bucket events, the per-bucket optimizer) and -- in a multi-rank RCCL job -- RCCL's internal stream: four.  The input
-  copy (``copy``) gets a stream of its own only while that leaves the total at four; in a multi-rank RCCL job it rides on
-  ``comm``, where it is submitted at the start of a step, long before the first bucket of that step is ready.
+* **Budget (performance).**  A rank owns exactly four streams: compute (the current stream), ``wgrad`` (weight gradients
+  beside the critical path), ``comm`` (bucket events, the per-bucket optimizer) and ``copy`` (the next batch's upload); a
+  fifth role is refused.  In a multi-rank RCCL job RCCL's internal stream comes on top, i.e. five streams on four hardware
+  queues, so two of them share a queue.  Folding the copy into ``comm`` or ``wgrad`` to stay at four was measured and is
+  WORSE: with every collective really issued through RCCL the step takes 62.0 ms (copy on ``comm``) or 64.0 ms (on
+  ``wgrad``) against 58.5 ms with a copy stream of its own (plain: 57.7; profiles/ab_copy_stream_r3.txt) -- an upload
+  queued on a stream that also carries kernels waits behind them and is waited for by the next step.  A shared hardware
+  queue costs only what one stream's packets delay the other's, and by the order argument above it cannot deadlock.
+  (``PDT_COPY_STREAM=comm|wgrad`` reproduces the measurement.)
 
 Upstream has no counterpart: it runs everything on the default stream plus DDP's internal ones
 (reference ``train_distributed.py:198,253-254``).
@@ -77,12 +81,13 @@ def get(role: str, device: torch.device, priority: Optional[int] = None) -> "tor
     s = _streams.get((dev, slot))
     if s is not None:
         return s
-    if role == "copy" and _library_streams():
-        s = get("comm", device)                   # the fourth stream belongs to RCCL: the copy rides on ``comm``
+    mode = os.environ.get("PDT_COPY_STREAM")        # A/B measurements: the copy on "comm" / "wgrad" instead of its own
+    if role == "copy" and mode in ("comm", "wgrad"):
+        s = get(mode, device)
     else:
-        if count(device) >= BUDGET:
+        if count(device) - _library_streams() >= BUDGET:
             raise RuntimeError(f"stream budget exceeded: {sorted(in_use(device))} are in use on cuda:{dev}, no room for "
-                               f"{role!r} (at most {BUDGET} streams per rank, RCCL's included)")
+                               f"{role!r} (at most {BUDGET} streams per rank besides the collective library's)")
         s = _masked_stream(role, device) or \
             torch.cuda.Stream(device=device, **({"priority": int(priority)} if priority is not None else {}))
     _streams[(dev, slot)] = s

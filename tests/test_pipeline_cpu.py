@@ -356,8 +356,8 @@ def test_list_program_host_actions(monkeypatch):
 
 
 def test_stream_budget_roles(monkeypatch):
-    """parallel/streams.py: one stream per role, the capture stream shares the weight-gradient slot, a fifth stream is
-    refused, and in a multi-rank RCCL job the input copy rides on the communication stream."""
+    """parallel/streams.py: one stream per role, the capture stream shares the weight-gradient slot, a fifth stream of
+    our own is refused; RCCL's internal stream is counted but does not take one of the four roles away."""
     import torch.distributed as dist
 
     from pytorch_distributed_training_amd.parallel import streams
@@ -376,14 +376,20 @@ def test_stream_budget_roles(monkeypatch):
         assert c is not cp and streams.count(dev) == 4 and sorted(streams.in_use(dev)) == ["comm", "compute", "copy", "wgrad"]
         with pytest.raises(RuntimeError, match="stream budget exceeded"):
             streams.get("another", dev)
-        # multi-rank RCCL job: RCCL owns the fourth stream
+        # multi-rank RCCL job: RCCL's stream comes on top of the four
         streams.reset()
         monkeypatch.setattr(dist, "is_initialized", lambda: True)
         monkeypatch.setattr(dist, "get_backend", lambda *a: "nccl")
         monkeypatch.setattr(dist, "get_world_size", lambda *a: 8)
         cp = streams.get("copy", dev)
-        assert streams.get("comm", dev) is cp
+        assert streams.get("comm", dev) is not cp
         streams.get("wgrad", dev)
-        assert streams.count(dev) == 4 and "rccl" in streams.in_use(dev)
+        assert streams.count(dev) == 5 and "rccl" in streams.in_use(dev)
+        with pytest.raises(RuntimeError, match="stream budget exceeded"):
+            streams.get("another", dev)
+        # the measurement switch: the copy on the communication stream
+        streams.reset()
+        monkeypatch.setenv("PDT_COPY_STREAM", "comm")
+        assert streams.get("copy", dev) is streams.get("comm", dev)
     finally:
         streams.reset()
