@@ -1,5 +1,7 @@
+# The GPU tier as one call: every GPU test, then the flagship bench, a BASELINE configuration by file, and the forced-collectives run
+# (gpurun --timeout 1190 -- bash bench/gpu_tier.sh).  Each step runs under its own time limit.
 set -o pipefail
-D=gpurun_out/r3g; mkdir -p $D
+D=gpurun_out/gpu_tier; mkdir -p $D
 timeout -k 10 1000 python -u -m pytest tests -m gpu -x -q --timeout 400 --timeout-method thread > $D/gpu_tests.log 2>&1; rc=$?; echo rc=$rc
 tail -5 $D/gpu_tests.log
 [ $rc -eq 0 ] || exit $rc
