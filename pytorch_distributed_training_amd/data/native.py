@@ -85,6 +85,9 @@ class RecordGatherer:
         return int(t)
 
     def wait(self, ticket: int) -> None:
+        if not self._h:                          # closed: close() joined the threads, nothing is in flight any more
+            self._keep.pop(int(ticket), None)
+            return
         rc = self._lib.pdt_batcher_wait(self._h, int(ticket))
         self._keep.pop(int(ticket), None)
         if rc == 1:
