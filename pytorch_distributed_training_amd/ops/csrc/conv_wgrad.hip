@@ -44,6 +44,7 @@ static const int g_pdt_wgrad_big_tile = env_int("PDT_WGRAD_BIG_TILE", 1);      /
 static const int g_pdt_wgrad_wide_small = env_int("PDT_WGRAD_WIDE_SMALL", 1);
 // 3x3 / stride 1 / padding 1: one kernel row per workgroup with the gathered operand staged once (0: one tap per workgroup)
 static const int g_pdt_wgrad_row3 = env_int("PDT_WGRAD_ROW3", 1);
+static const int g_pdt_wgrad_row3_min_w = env_int("PDT_WGRAD_ROW3_MIN_W", 0);   // ... on images at least this wide
 
 #define MAX_TAPS 52
 #define BKP 64   // pixels per K step
@@ -1091,7 +1092,7 @@ PDT_API int pdt_conv_wgrad_ex(const void* dy, const void* in, float* dw, long lo
     const int auto_mb = images >= 1024 ? 32 : 24;
     long long budget = (long long)(atomic_budget_mb > 0 ? atomic_budget_mb
                                    : (g_pdt_wgrad_atomic_mb > 0 ? g_pdt_wgrad_atomic_mb : auto_mb)) << 20;
-    if (tile == 0 && g_pdt_wgrad_row3 && Ci >= 64 && row3_applies(p)) tile = N <= 64 ? 11 : 10;
+    if (tile == 0 && g_pdt_wgrad_row3 && Ci >= 64 && Wi >= g_pdt_wgrad_row3_min_w && row3_applies(p)) tile = N <= 64 ? 11 : 10;
     if (tile == 0) {
         if (Ci <= 32) tile = (T == 7) ? 5 : 3;
         else if (T == 9 && Ci <= 64) tile = (N <= 64) ? 6 : 7;    // 3x3 on 64 channels: one kernel row per workgroup
