@@ -376,6 +376,8 @@ def main() -> int:
                 "exposed_comm_ms_per_step": round(exposed, 4) if exposed is not None else None,
                 "optimizer_in_backward": engine.model.optimizer_in_backward if native else None,
                 "comm_healthy": bool(healthy),
+                # payload reads the in-kernel exchange had to repeat on this rank (checksum not matching yet)
+                "xgmi_payload_rereads": (engine.model._xgmi.rereads() if native and engine.model._xgmi is not None else None),
                 "host_submit_ms_per_step": round(1e3 * enqueue / args.steps, 3),
                 "syncbn_comm": engine.model.syncbn_comm if (args.engine == "native" and engine.model.sync_bn) else None,
                 "step_replay": replay_mode,

@@ -39,8 +39,8 @@ PDT_API int pdt_car_create(int world, int rank, int max_floats, void** out) {
     hipError_t e = hipExtMallocWithFlags(&h->local_base, h->local_bytes, hipDeviceMallocFinegrained);
     if (e != hipSuccess) { delete h; return (int)e; }
     e = hipMemset(h->local_base, 0, h->local_bytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->seq_status, 2 * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMemset(h->seq_status, 0, 2 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->seq_status, 4 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(h->seq_status, 0, 4 * sizeof(unsigned));
     void* pinned_dev = nullptr;
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->status_pinned, 64, hipHostMallocMapped);
     if (e == hipSuccess) {
@@ -57,6 +57,7 @@ PDT_API int pdt_car_create(int world, int rank, int max_floats, void** out) {
     }
     h->dev.seq = h->seq_status;
     h->dev.status = h->seq_status + 1;
+    h->dev.rereads = h->seq_status + 2;
     h->dev.status_host = static_cast<unsigned*>(pinned_dev);
     h->dev.flags = reinterpret_cast<unsigned*>(h->local_base);
     h->dev.recv = reinterpret_cast<float4*>(static_cast<char*>(h->local_base) + car_recv_offset());
@@ -135,11 +136,11 @@ PDT_API int pdt_car_allreduce_chunks(void* handle, float* data, long long n, hip
     return pdt_launch_status();
 }
 
-// Synchronous read of [sequence number, status] (status != 0: a wait timed out).
-PDT_API int pdt_car_query(void* handle, unsigned* out2) {
+// Synchronous read of [sequence number, status, payload re-reads] (status != 0: a wait timed out or a checksum failed).
+PDT_API int pdt_car_query(void* handle, unsigned* out3) {
     CarHost* h = static_cast<CarHost*>(handle);
-    if (!h || !out2) return -2;
-    return (int)hipMemcpy(out2, h->seq_status, 2 * sizeof(unsigned), hipMemcpyDeviceToHost);
+    if (!h || !out3) return -2;
+    return (int)hipMemcpy(out3, h->seq_status, 3 * sizeof(unsigned), hipMemcpyDeviceToHost);
 }
 
 // Status word as last written to pinned host memory: no synchronisation, no GPU call.  May lag

@@ -44,6 +44,7 @@ struct CarDev {
     int max4;                      // capacity of one slot in float4 units
     unsigned* seq;                 // device counter (local, ordinary memory)
     unsigned* status;              // non-zero after a timeout (local)
+    unsigned* rereads;             // payload reads repeated because a checksum did not match yet (local, diagnostic)
     unsigned* status_host;         // the same, in pinned host memory (device-visible address)
     unsigned* flags;               // local flags [2][CAR_MAX_WORLD], checksums [2][CAR_MAX_WORLD] at word CAR_CHK_OFFSET
     float4* recv;                  // local receive buffer [2][world][max4]
@@ -58,7 +59,7 @@ struct CarHost {
     void* local_base;              // fine-grained allocation: flags then receive buffer
     size_t local_bytes;
     void* opened[CAR_MAX_WORLD];   // IPC mappings to close
-    unsigned* seq_status;          // ordinary device memory: [seq, status]
+    unsigned* seq_status;          // ordinary device memory: [seq, status, rereads]
     unsigned* status_pinned;       // host address of the pinned status word
 };
 
@@ -173,6 +174,7 @@ __device__ __forceinline__ bool car_exchange_block(const CarDev& d, float* vals,
             if (tid == 0) ctl[2] = ok ? 1u : 0u;
             __syncthreads();
             if (ctl[2]) break;
+            if (tid == 0) atomicAdd(d.rereads, 1u);      // seen on real links = the flag does overtake payload words there
             if (attempt >= CAR_READ_RETRIES) {
                 if (tid == 0) ctl[1] = 2u;
                 __syncthreads();

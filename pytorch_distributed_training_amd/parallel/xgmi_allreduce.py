@@ -120,10 +120,19 @@ class XgmiAllReduce:
 
     def status(self) -> int:
         """Synchronises; non-zero when a wait inside a kernel timed out (results invalid)."""
-        out = (ctypes.c_uint * 2)()
+        out = (ctypes.c_uint * 3)()
         if self._lib.pdt_car_query(self._h, out) != 0:
             return -1
         return int(out[1])
+
+    def rereads(self) -> int:
+        """Synchronises; how often a payload had to be read again because its checksum did not match yet (the flag had
+        overtaken payload words).  Zero between processes on one GPU; on real links it is the measure of how much the
+        fence-free ordering is being leaned on.  -1 if the query failed."""
+        out = (ctypes.c_uint * 3)()
+        if self._lib.pdt_car_query(self._h, out) != 0:
+            return -1
+        return int(out[2])
 
     def peek(self) -> int:
         """The status as last written to pinned host memory: no synchronisation, no GPU call; may

@@ -63,10 +63,12 @@ def _one_rank_worker():
         torch.cuda.synchronize()
         out["graph_identity"] = bool(torch.equal(t, ref)) and x.status() == 0
         # a payload whose checksum does not match what was read is refused: NaN result, status 2 (not a timeout)
+        clean = x.rereads()                              # nothing had to be read twice so far
         x._lib.pdt_car_corrupt_checksum(x._h, 0x10)
         bad = torch.ones(512, device=dev)
         x.all_reduce(bad)
         out["checksum_refused"] = bool(torch.isnan(bad).all()) and x.status() == 2 and x.peek() == 2
+        out["rereads"] = [clean, x.rereads()]            # ... and the refused payload was re-read the bounded number of times
         x.close()
     dist.destroy_process_group()
     print("RESULT " + json.dumps(out), flush=True)
@@ -79,7 +81,7 @@ def test_single_rank_protocol_and_graph_replay():
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     assert out == {"created": True, "self_test": True, "identity": True, "status": 0, "healthy": True,
-                   "graph_identity": True, "checksum_refused": True}, out
+                   "graph_identity": True, "checksum_refused": True, "rereads": [0, 65]}, out
 
 
 def _two_rank_worker(rank, port, provoke_timeout):
