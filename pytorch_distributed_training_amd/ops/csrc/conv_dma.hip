@@ -66,6 +66,7 @@ struct ConvDmaParams {
     int Ho, Wo, OS, oy0, ox0;          // ... and is written to output pixel (y*OS + oy0, x*OS + ox0)
     int wrow, T;                       // weight row length (elements), taps
     int simple_out;                    // output row == GEMM row
+    unsigned magic_w, magic_h;         // 2^20 / Wg + 1, 2^20 / Hg + 1: exact multiply-shift division of small offsets
     int addend_half;                   // addend is [B][Ho/2][Wo/2][N], present at even output (y, x) only
     int nrep;                          // replica rows of the statistics accumulator (see common.h)
     const bf16* in2;                   // second operand [M][pix_stride2] (may be null), reduced after the taps
@@ -725,9 +726,29 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
                 }
             }
         } else {
+        // GENERIC EPILOGUE (output rows scattered over a strided grid -- the output-parity classes of a stride-2 data
+        // gradient -- or the addend at half resolution): every row has an address of its own, so operands go through flat
+        // 64-bit addresses; what is shared with the lean path is the arithmetic on packed bf16 pairs.  The row's position
+        // on the GEMM grid is NOT divided out per row (two 32-bit divisions are ~60 vector instructions, per row group):
+        // the wave tile's first row is decomposed once per tile on wave-uniform values, and a row is that position plus
+        // i * 16 + frow, carried into (x, y, image) with multiply-shift divisions that are exact for the few hundred
+        // values that can occur (launcher: magic = 2^20 / d + 1, (d + 256) d < 2^20).
         // Epilogue operands of EG row groups first, so they are all in flight together: all MI of them, except with
         // the backward-sums epilogue on a 64-row wave tile, where four groups of loads on top of the 80 registers of
         // sums and per-channel constants would not fit 256 VGPRs -- two passes of two groups there.
+        static_assert(!(GEN && FOLD), "the second-operand launches are 1x1 / dense: lean epilogue only");
+        const bool grid_pos = !p.simple_out || p.addend_half;
+        const int roww = m0 + wm * WTM;                                   // first row of the wave tile (wave-uniform)
+        const bool any_live = roww < p.M;
+        unsigned gb0 = 0, gy0 = 0, gx0 = 0;
+        if (grid_pos) {
+            const unsigned mw = (unsigned)__builtin_amdgcn_readfirstlane(any_live ? roww : p.M - 1);
+            gb0 = mw / (unsigned)HgWg;
+            const unsigned rem = mw - gb0 * (unsigned)HgWg;
+            gy0 = rem / (unsigned)p.Wg;
+            gx0 = rem - gy0 * (unsigned)p.Wg;
+        }
+        const size_t orow0 = (size_t)(any_live ? roww : p.M - 1);
 #pragma unroll
         for (int i0 = 0; i0 < MI; i0 += EG) {
         size_t oidx[EG];
@@ -737,15 +758,14 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
 #pragma unroll
         for (int e = 0; e < EG; ++e) {
             const int i = i0 + e;
-            const int mi = m0 + wm * WTM + i * 16 + frow;
-            live[e] = mi < p.M;
-            const int m = live[e] ? mi : p.M - 1;
+            live[e] = roww + i * 16 + frow < p.M;
+            const unsigned t = live[e] ? (unsigned)(i * 16 + frow) : 0u;   // rows past the end: the tile's first row (loads stay inside)
             unsigned yo = 0, xo = 0, bimg = 0;
-            size_t orow = (size_t)m;
-            if (!p.simple_out || p.addend_half) {
-                bimg = (unsigned)m / (unsigned)HgWg;
-                const unsigned rem = (unsigned)m - bimg * (unsigned)HgWg;
-                const unsigned y = rem / (unsigned)p.Wg, x = rem - y * (unsigned)p.Wg;
+            size_t orow = orow0 + t;
+            if (grid_pos) {
+                const unsigned tx = gx0 + t, qx = (tx * p.magic_w) >> 20, x = tx - qx * (unsigned)p.Wg;
+                const unsigned ty = gy0 + qx, qy = (ty * p.magic_h) >> 20, y = ty - qy * (unsigned)p.Hg;
+                bimg = gb0 + qy;
                 yo = y * (unsigned)p.OS + (unsigned)p.oy0;
                 xo = x * (unsigned)p.OS + (unsigned)p.ox0;
                 if (!p.simple_out) orow = ((size_t)bimg * p.Ho + yo) * p.Wo + xo;
@@ -777,7 +797,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
         for (int e = 0; e < EG; ++e) {
             const int i = i0 + e;
             // register r of block j holds channel 16*fq + 4*j + r of this lane's pixel (see g1_swz_w); the value (plus the
-            // addend) is rounded to bf16 ONCE, and everything after that works on what will be stored
+            // addend) is rounded to bf16 ONCE, and everything after that works on the packed pairs that will be stored
             float val[16];
 #pragma unroll
             for (int j = 0; j < NI; ++j)
@@ -794,83 +814,73 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
                         val[k + 1] += bf_hi(a);
                     }
             }
+            unsigned pk[8];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) val[k] = bf2f(f2bf(val[k]));
+            for (int d = 0; d < 8; ++d) pk[d] = pack2(val[d * 2], val[d * 2 + 1]);
             if (has_mask) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) val[k] = ((mb[e] >> k) & 1u) ? val[k] : 0.0f;
-            }
-            if (FOLD && !BSTAT && p.relu_out) {              // (forward tails only: no backward-sums epilogue there)
-#pragma unroll
-                for (int k = 0; k < 16; ++k) val[k] = fmaxf(val[k], 0.0f);
-            }
-            if (FOLD && !BSTAT && p.bits_out && live[e]) {
-                unsigned m16 = 0;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) m16 |= (val[k] > 0.0f ? 1u : 0u) << k;
-                *reinterpret_cast<unsigned short*>(p.bits_out + (oidx[e] >> 3)) = (unsigned short)m16;
+                for (int d = 0; d < 8; ++d) {
+                    const unsigned lo = (unsigned)__builtin_amdgcn_sbfe((int)mb[e], 2 * d, 1);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_sbfe((int)mb[e], 2 * d + 1, 1);
+                    pk[d] &= (lo & 0xffffu) | (hi & ~0xffffu);
+                }
             }
             // (order chosen per variant by the register allocation it leads to: the backward-sums variants spill otherwise)
             auto add_stats = [&]() {
-    if (live[e]) {
-                    if (BSTAT) {
+                if (!live[e]) return;
+                if constexpr (BSTAT) {
 #pragma unroll
-                        for (int h = 0; h < 2; ++h)
+                    for (int h = 0; h < 2; ++h)
 #pragma unroll
-                            for (int d = 0; d < 4; ++d) {
-                                const unsigned yy2 = yv[e][h][d];
-                                const int k = h * 8 + d * 2;
-                                float y0 = bf_lo(yy2), y1 = bf_hi(yy2);
-                                float d0 = val[k], d1 = val[k + 1];
-                                if (bwd_mask) {
-                                    d0 = (y0 * msc[k] + msh[k]) > 0.0f ? d0 : 0.0f;
-                                    d1 = (y1 * msc[k + 1] + msh[k + 1]) > 0.0f ? d1 : 0.0f;
-                                }
-                                s0[k] += d0;
-                                s1[k] += d0 * (y0 - ctr[k]);
-                                s0[k + 1] += d1;
-                                s1[k + 1] += d1 * (y1 - ctr[k + 1]);
+                        for (int d = 0; d < 4; ++d) {
+                            const unsigned yy2 = yv[e][h][d], pp = pk[h * 4 + d];
+                            const int k = h * 8 + d * 2;
+                            const float y0 = bf_lo(yy2), y1 = bf_hi(yy2);
+                            float d0 = bf_lo(pp), d1 = bf_hi(pp);
+                            if (bwd_mask) {
+                                d0 = (y0 * msc[k] + msh[k]) > 0.0f ? d0 : 0.0f;
+                                d1 = (y1 * msc[k + 1] + msh[k + 1]) > 0.0f ? d1 : 0.0f;
                             }
-                    } else if (want_stats) {
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) {
-                            const float d = val[k] - ctr[k];
-                            s0[k] += d;
-                            s1[k] += d * d;
+                            s0[k] += d0;
+                            s1[k] += d0 * (y0 - ctr[k]);
+                            s0[k + 1] += d1;
+                            s1[k + 1] += d1 * (y1 - ctr[k + 1]);
                         }
+                } else if constexpr (NOSTATS || PF) {
+                } else if (want_stats) {
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) {
+                        const float a = bf_lo(pk[d]) - ctr[2 * d], b = bf_hi(pk[d]) - ctr[2 * d + 1];
+                        s0[2 * d] += a;
+                        s1[2 * d] += a * a;
+                        s0[2 * d + 1] += b;
+                        s1[2 * d + 1] += b * b;
                     }
                 }
             };
             auto store_result = [&]() {
-    {
-                    // Result stores in whole 128-byte lines: lane (fq, frow) holds bytes [32 fq, 32 fq + 32) of its pixel's
-                    // 128-byte segment; lanes frow and frow ^ 8 trade one 16-byte half (a rotation by 8 inside the row of 16
-                    // lanes), after which the eight lanes (fq, frow & 8) hold the eight 16-byte pieces of ONE pixel: a store
-                    // instruction writes 8 full lines instead of 16 rows x 4 pieces of 16 bytes at a stride of 32 (streaming
-                    // stores in that split pattern reach 2.2 TB/s, in whole lines 5.2: bench/diag/store_pattern.hip).
-                    u32x4 o0, o1;
+                // Result stores in whole 128-byte lines: lane (fq, frow) holds bytes [32 fq, 32 fq + 32) of its pixel's
+                // 128-byte segment; lanes frow and frow ^ 8 trade one 16-byte half (a rotation by 8 inside the row of 16
+                // lanes), after which the eight lanes (fq, frow & 8) hold the eight 16-byte pieces of ONE pixel: a store
+                // instruction writes 8 full lines instead of 16 rows x 4 pieces of 16 bytes at a stride of 32 (streaming
+                // stores in that split pattern reach 2.2 TB/s, in whole lines 5.2: bench/diag/store_pattern.hip).
+                const u32x4 o0 = {pk[0], pk[1], pk[2], pk[3]}, o1 = {pk[4], pk[5], pk[6], pk[7]};
+                const bool up = (frow & 8) != 0;
+                u32x4 got;
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        o0[d] = pack2(val[d * 2], val[d * 2 + 1]);
-                        o1[d] = pack2(val[8 + d * 2], val[8 + d * 2 + 1]);
-                    }
-                    const bool up = (frow & 8) != 0;
-                    u32x4 got;
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) got[d] = dpp_xor8(up ? o0[d] : o1[d]);
-                    // the partner's output element (a multiple of 16, so bit 0 carries "row past the end") as a signed
-                    // 32-bit distance from this lane's: the two pixels are at most a few images apart
-                    const unsigned mine = (unsigned)oidx[e] | (live[e] ? 0u : 1u);
-                    const unsigned other = dpp_xor8(mine);
-                    const int dist = (int)((other & ~1u) - (unsigned)oidx[e]);
-                    // piece 2 fq + (frow >> 3) of the pixel of lane frow & 7 (first) and of lane 8 + (frow & 7) (second)
-                    const bool ok_first = !((up ? other : mine) & 1u), ok_second = !((up ? mine : other) & 1u);
-                    bf16* o_first = p.out + oidx[e] + (up ? dist + 8 : 0);
-                    bf16* o_second = p.out + oidx[e] + (up ? 8 : dist);
-                    const u32x4 v_first = up ? got : o0, v_second = up ? o1 : got;
-                    if (ok_first && !DIAG(1)) __builtin_nontemporal_store(v_first, reinterpret_cast<u32x4*>(o_first));
-                    if (ok_second && !DIAG(1)) __builtin_nontemporal_store(v_second, reinterpret_cast<u32x4*>(o_second));
-                }
+                for (int d = 0; d < 4; ++d) got[d] = dpp_xor8(up ? o0[d] : o1[d]);
+                // the partner's output element (a multiple of 16, so bit 0 carries "row past the end") as a signed
+                // 32-bit distance from this lane's: the two pixels are at most a few images apart
+                const unsigned mine = (unsigned)oidx[e] | (live[e] ? 0u : 1u);
+                const unsigned other = dpp_xor8(mine);
+                const int dist = (int)((other & ~1u) - (unsigned)oidx[e]);
+                // piece 2 fq + (frow >> 3) of the pixel of lane frow & 7 (first) and of lane 8 + (frow & 7) (second)
+                const bool ok_first = !((up ? other : mine) & 1u), ok_second = !((up ? mine : other) & 1u);
+                bf16* o_first = p.out + oidx[e] + (up ? dist + 8 : 0);
+                bf16* o_second = p.out + oidx[e] + (up ? 8 : dist);
+                const u32x4 v_first = up ? got : o0, v_second = up ? o1 : got;
+                if (ok_first && !DIAG(1)) __builtin_nontemporal_store(v_first, reinterpret_cast<u32x4*>(o_first));
+                if (ok_second && !DIAG(1)) __builtin_nontemporal_store(v_second, reinterpret_cast<u32x4*>(o_second));
             };
             if (BSTAT) {
                 store_result();
@@ -1000,6 +1010,9 @@ PDT_API int pdt_conv_dma_ex(const void* in, const void* wgt, void* out, const vo
     p.Hg = Hg; p.Wg = Wg; p.IS = IS; p.Ho = Ho; p.Wo = Wo; p.OS = OS; p.oy0 = oy0; p.ox0 = ox0;
     p.wrow = wrow; p.T = T;
     p.simple_out = (OS == 1 && oy0 == 0 && ox0 == 0 && Hg == Ho && Wg == Wo) ? 1 : 0;
+    if ((long long)(Wg + 256) * Wg >= (1 << 20) || (long long)(Hg + 256) * Hg >= (1 << 20)) return -13;
+    p.magic_w = (1u << 20) / (unsigned)Wg + 1u;
+    p.magic_h = (1u << 20) / (unsigned)Hg + 1u;
     p.addend_half = (addend && addend_half) ? 1 : 0;
     p.nrep = pdt_nrep();
     p.in2 = (const bf16*)in2; p.bias = bias; p.Ci2 = Ci2; p.pix_stride2 = in2 ? pix_stride2 : 0;
