@@ -67,6 +67,7 @@ struct ConvDmaParams {
     int wrow, T;                       // weight row length (elements), taps
     int simple_out;                    // output row == GEMM row
     unsigned magic_w, magic_h;         // 2^20 / Wg + 1, 2^20 / Hg + 1: exact multiply-shift division of small offsets
+    unsigned long long addend_half_bytes;   // size of the half-resolution addend tensor (addend_half)
     int addend_half;                   // addend is [B][Ho/2][Wo/2][N], present at even output (y, x) only
     int nrep;                          // replica rows of the statistics accumulator (see common.h)
     const bf16* in2;                   // second operand [M][pix_stride2] (may be null), reduced after the taps
@@ -414,14 +415,40 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
         const unsigned long long m_addr = (unsigned long long)p.mask_bits + (e0 >> 3);
         const int row16 = 16 * p.N * 2;
         const unsigned bit_off = ep_ld >> 4;
+        // Addend at HALF resolution (the gradient of a stride-2 1x1 shortcut, present at the even pixels only): one
+        // descriptor per wave tile, based at the half-resolution image of the tile's first row, and a per-lane offset --
+        // the row's position carried from one per-tile decomposition by exact multiply-shift divisions -- that points
+        // past the descriptor for odd pixels and rows past the end, so those lanes receive the zeros they need.
+        const bool half = p.addend_half != 0;                              // workgroup-uniform
+        unsigned hy0 = 0, hx0 = 0, h_nrec = 0;
+        unsigned long long h_addr = 0;
+        const unsigned Hh = (unsigned)p.Ho >> 1, Wh = (unsigned)p.Wo >> 1;
+        if (half) {
+            const unsigned mw = (unsigned)(row0 < p.M ? row0 : p.M - 1);
+            const unsigned hb0 = mw / (unsigned)HgWg, rem = mw - hb0 * (unsigned)HgWg;
+            hy0 = rem / (unsigned)p.Wg;
+            hx0 = rem - hy0 * (unsigned)p.Wg;
+            const unsigned long long base = ((unsigned long long)hb0 * Hh * Wh * (unsigned)p.N + (unsigned)(n0 + wn * WTN)) * 2ull;
+            const unsigned long long left = p.addend_half_bytes > base ? p.addend_half_bytes - base : 0ull;
+            h_addr = (unsigned long long)p.addend + base;
+            h_nrec = (live && pf_addend) ? (left < 0x7fff0000ull ? (unsigned)left : 0x7fff0000u) : 0u;
+        }
 #pragma unroll
         for (int e = 0; e < PMI; ++e) {
             // (the row group's offset is part of the descriptor's base: the range check never sees a scalar offset)
             int have = rows_left - e * 16;
             have = have < 0 ? 0 : (have > 16 ? 16 : have);
             const unsigned nrec = (unsigned)(have * p.N * 2);
-            const unsigned long long a_e = a_addr + (unsigned)(e * row16), m_e = m_addr + (unsigned)((e * row16) >> 4);
-            const u32x4 a_desc = {(unsigned)a_e, (unsigned)(a_e >> 32) & 0xffffu, pf_addend ? nrec : 0u, 0x00020000u};
+            unsigned a_off = ep_ld;
+            if (half) {
+                const unsigned t = (unsigned)(e * 16 + frow);
+                const unsigned tx = hx0 + t, qx = (tx * p.magic_w) >> 20, x = tx - qx * (unsigned)p.Wg;
+                const unsigned ty = hy0 + qx, qy = (ty * p.magic_h) >> 20, y = ty - qy * (unsigned)p.Hg;
+                const bool ok = !((x | y) & 1u) && (int)t < rows_left;
+                a_off = ok ? ((qy * Hh + (y >> 1)) * Wh + (x >> 1)) * (unsigned)(p.N * 2) + (unsigned)(fq * 32) : PDT_OOB_OFFSET;
+            }
+            const unsigned long long a_e = half ? h_addr : a_addr + (unsigned)(e * row16), m_e = m_addr + (unsigned)((e * row16) >> 4);
+            const u32x4 a_desc = {(unsigned)a_e, (unsigned)(a_e >> 32) & 0xffffu, half ? h_nrec : (pf_addend ? nrec : 0u), 0x00020000u};
             const u32x4 m_desc = {(unsigned)m_e, (unsigned)(m_e >> 32) & 0xffffu, pf_mask ? nrec >> 4 : 0u, 0x00020000u};
             // (s_nop 4: the scalar registers may have been written by the instructions just before)
             asm volatile(
@@ -430,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvDmaParams p)
                 "buffer_load_dwordx4 %1, %3, %4, 0 offen offset:16 nt\n\t"
                 "buffer_load_ushort %2, %5, %6, 0 offen"
                 : "=&v"(nav[e][0]), "=&v"(nav[e][1]), "=&v"(nmb[e])
-                : "v"(ep_ld), "s"(a_desc), "v"(bit_off), "s"(m_desc)
+                : "v"(a_off), "s"(a_desc), "v"(bit_off), "s"(m_desc)
                 : "memory");
         }
     };
@@ -940,13 +967,14 @@ template <int BN, int WM, int WN, int BK, int R, bool BSTAT, bool FOLD = false>
 static int g1_launch(const ConvDmaParams& p, hipStream_t s) {
     // the lean epilogue wants output row == GEMM row and a full-resolution addend (always true with a second operand /
     // start values: the launcher admits only the plain 1x1 geometry there)
+    // the prefetching variant: epilogue operands to hide, and statistics (if any) that are plain sums
+    const bool pf = !BSTAT && R == 2 && g_dma_prefetch && (p.addend || p.mask_bits) && (!p.stat_acc || p.sums_only);
     if constexpr (!FOLD) {
-        if (!p.simple_out || p.addend_half) return g1_launch_of<BN, WM, WN, BK, R, BSTAT, false, true, false>(p, s);
+        // (an addend at half resolution is understood by the prefetching variant and the generic one only)
+        if (!p.simple_out || (p.addend_half && !pf)) return g1_launch_of<BN, WM, WN, BK, R, BSTAT, false, true, false>(p, s);
     }
     if constexpr (!BSTAT && R == 2) {
-        // epilogue operands to hide, and statistics (if any) that are plain sums
-        if (g_dma_prefetch && (p.addend || p.mask_bits) && (!p.stat_acc || p.sums_only))
-            return g1_launch_of<BN, WM, WN, BK, R, false, FOLD, false, true>(p, s);
+        if (pf) return g1_launch_of<BN, WM, WN, BK, R, false, FOLD, false, true>(p, s);
     }
     return g1_launch_of<BN, WM, WN, BK, R, BSTAT, FOLD, false, false>(p, s);
 }
@@ -1013,6 +1041,7 @@ PDT_API int pdt_conv_dma_ex(const void* in, const void* wgt, void* out, const vo
     if ((long long)(Wg + 256) * Wg >= (1 << 20) || (long long)(Hg + 256) * Hg >= (1 << 20)) return -13;
     p.magic_w = (1u << 20) / (unsigned)Wg + 1u;
     p.magic_h = (1u << 20) / (unsigned)Hg + 1u;
+    p.addend_half_bytes = (addend && addend_half) ? (unsigned long long)(M / ((long long)Hg * Wg)) * (Ho >> 1) * (Wo >> 1) * N * 2ull : 0ull;
     p.addend_half = (addend && addend_half) ? 1 : 0;
     p.nrep = pdt_nrep();
     p.in2 = (const bf16*)in2; p.bias = bias; p.Ci2 = Ci2; p.pix_stride2 = in2 ? pix_stride2 : 0;

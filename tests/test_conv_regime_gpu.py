@@ -143,6 +143,38 @@ def test_first_conv_dgrad_of_a_downsampling_block(hip, device, B, H, Ci, Co, til
     assert torch.allclose(dg1, dg0, rtol=2e-3, atol=tol) and torch.allclose(db1, db0, rtol=2e-3, atol=tol)
 
 
+@pytest.mark.parametrize("out_sums", [False, True])
+@pytest.mark.parametrize("B,H,Ci,Co,tile", [(16, 56, 128, 256, 0), (3, 14, 512, 1024, 0), (5, 6, 64, 128, 0), (64, 28, 256, 512, 0),
+                                            (7, 10, 64, 64, 0), (16, 56, 128, 256, -2)])
+def test_half_resolution_addend_in_the_prefetching_epilogue(hip, device, B, H, Ci, Co, tile, out_sums):
+    """The same data gradient without backward sums of a BatchNorm (the previous block's tail is folded): that launch
+    takes the prefetching epilogue, which fetches the half-resolution addend through one descriptor per wave tile and
+    per-lane offsets (odd pixels and rows past the end point past the descriptor and read zeros).  Tiles that span
+    several small images, a partial last tile, both tile shapes, with and without the plain sums of the result."""
+    torch.manual_seed(B * 7 + H + Ci)
+    dy = rnd(B, H, H, Ci, device=device)
+    w = rnd(Ci, 1, 1, Co, device=device, scale=(2.0 / Co) ** 0.5)
+    wt = torch.empty(Co, 1, 1, Ci, dtype=torch.bfloat16, device=device)
+    hip.transpose_weights(w, wt)
+    shape = (B, H, H, Co)
+    half = rnd(B, H // 2, H // 2, Co, device=device)
+    x_act = torch.relu(rnd(*shape, device=device))
+    bits = hip.new_relu_bits(x_act)
+    ref._pack_bits(x_act, bits)
+    g = hip.conv_dgrad(dy, w, wt, shape, 1, 1, 1, 0, addend=half, addend_half=True, relu_bits=bits, tile=tile,
+                       out_sums=out_sums)
+    g_ref = ref.conv_dgrad(dy, w, None, shape, 1, 1, 1, 0, addend=half, addend_half=True, relu_bits=bits)
+    assert max_rel(g, g_ref) < 1.5e-2 and rel_l2(g, g_ref) < 4e-3
+    # the addend is there at the even pixels and nowhere else
+    plain = ref.conv_dgrad(dy, w, None, shape, 1, 1, 1, 0, relu_bits=bits)
+    odd = (g.float() - plain.float())[:, 1::2, :, :]
+    assert odd.abs().max() < 2e-2 * plain.float().abs().max()
+    if out_sums:
+        sums = hip.grad_sums(Co, device)
+        want = g.float().reshape(-1, Co).sum(0)
+        assert torch.allclose(sums, want, rtol=2e-3, atol=2e-3 * float(want.abs().max()))
+
+
 WGRAD = [
     (16, 56, 64, 256, 1, 1, 0, 0), (64, 56, 64, 64, 3, 1, 1, 0), (64, 28, 128, 128, 3, 1, 1, 1),
     (64, 28, 512, 128, 1, 1, 0, 1), (64, 14, 256, 256, 3, 1, 1, 1), (64, 14, 1024, 256, 1, 1, 0, 2),

@@ -62,12 +62,15 @@ def _per_tensor_cos(a, b):
 
 
 # (model, probe batch, image size, conditioning steps, floor of the bf16 REFERENCE engine's per-tensor cosine to fp32,
-#  floor of its whole-gradient cosine): floors measured on this construction, with margin
-CASES = [("ResNet18", 64, 128, 12, 0.95, 0.985), ("ResNet50", 64, 128, 14, 0.85, 0.93)]
+#  floor of its whole-gradient cosine, per-tensor margin of the HIP engine against the bf16 reference): measured on this
+#  construction, with margin.  ResNet-50's worst tensors (BatchNorm biases of the first stage) sit at 0.88-0.93 for BOTH
+#  bf16 implementations and move by +-0.04 from run to run (the conditioning itself is not bit-reproducible), hence the
+#  wider margin there; a sign error in one layer scores -0.9 (see the test below).
+CASES = [("ResNet18", 64, 128, 12, 0.95, 0.985, 0.04), ("ResNet50", 64, 128, 14, 0.85, 0.93, 0.08)]
 
 
-@pytest.mark.parametrize("name,B,H,steps,floor_tensor,floor_whole", CASES)
-def test_hip_engine_against_fp32_on_a_conditioned_network(device, monkeypatch, name, B, H, steps, floor_tensor, floor_whole):
+@pytest.mark.parametrize("name,B,H,steps,floor_tensor,floor_whole,margin", CASES)
+def test_hip_engine_against_fp32_on_a_conditioned_network(device, monkeypatch, name, B, H, steps, floor_tensor, floor_whole, margin):
     from pytorch_distributed_training_amd.ops import hip
     spec, sd, proto = conditioned_state(name, device, H, B, steps)
     img, label = _batch(proto, B, 999, device)
@@ -110,7 +113,7 @@ def test_hip_engine_against_fp32_on_a_conditioned_network(device, monkeypatch, n
         # 2. as close to fp32 as a known-good bf16 implementation, tensor by tensor
         assert abs(lh - l32) <= 0.01 * max(abs(l32), 1e-3) + 2e-3, (lh, l32)
         assert whole >= pre_whole - 0.01, (whole, pre_whole)
-        bad = {k: (v, pre[k]) for k, v in got.items() if v < min(pre[k], 0.995) - 0.04}
+        bad = {k: (v, pre[k]) for k, v in got.items() if v < min(pre[k], 0.995) - margin}
         assert not bad, f"fold={fold}: tensors further from fp32 than the bf16 reference: {dict(list(bad.items())[:6])}"
         # 3. running statistics (updated once by this step)
         assert nerr(eng.running_mean, f32.running_mean) < 1e-2 and nerr(eng.running_var, f32.running_var) < 1e-2
@@ -120,7 +123,7 @@ def test_a_wrong_sign_in_one_layer_fails_the_oracle(device):
     """The yardstick has teeth: flipping the sign of ONE deep layer's weight gradient (what a sign error in that layer's
     fused epilogue would do to it, and only to it) is far outside what the oracle accepts."""
     from pytorch_distributed_training_amd.ops import hip
-    name, B, H, steps, floor_tensor, _ = CASES[0]
+    name, B, H, steps, floor_tensor, _, _ = CASES[0]
     spec, sd, proto = conditioned_state(name, device, H, B, steps)
     img, label = _batch(proto, B, 999, device)
     f32 = NativeResNet(spec, device, ref, torch.float32)
