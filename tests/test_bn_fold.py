@@ -392,23 +392,30 @@ def test_hip_engine_with_the_width_limit_of_the_fold(hip, device, monkeypatch):
     label = torch.randint(0, 10, (8,), device=device)
     monkeypatch.setenv("PDT_BN_FOLD_MIN_MB", "0")
     monkeypatch.setenv("PDT_FWD_FUSE", "0")              # same forward pass in all three, so gradients compare tightly
+    # ordered reductions: with float atomics the batch statistics differ in their last bit from run to run, and on this
+    # randomly initialised network one flipped bf16 rounding moves the loss by 0.01-0.03 -- the forward passes below
+    # are the same arithmetic and must give the same loss, which only holds bit for bit
+    hip.set_deterministic(True)
     grads, losses = [], []
-    for on, limit in (("1", "1024"), ("1", "0"), ("0", "0")):
-        monkeypatch.setenv("PDT_BN_FOLD", on)
-        monkeypatch.setenv("PDT_BN_FOLD_MAX_COUT", limit)
-        eng = NativeResNet(get_spec("ResNet50", 10), device, hip, torch.bfloat16, hip_graphs=True)
-        eng.load_state_dict(state)
-        last4 = eng.spec.blocks[-1].units[-1]
-        assert eng._can_fold(last4, 1 << 30) == (on == "1" and limit == "0")
-        assert eng._can_fold(eng.spec.blocks[0].units[-1], 1 << 30) == (on == "1")
-        for _ in range(3):                               # eager, recorded, replayed
-            loss = float(eng.forward_backward(img, label))
-            torch.cuda.synchronize()
-            last = eng.params.g.clone()
-            eng.params.g.zero_()
-        losses.append(loss)
-        grads.append(last)
-    assert abs(losses[0] - losses[2]) < 1e-3 and abs(losses[1] - losses[2]) < 1e-3
+    try:
+        for on, limit in (("1", "1024"), ("1", "0"), ("0", "0")):
+            monkeypatch.setenv("PDT_BN_FOLD", on)
+            monkeypatch.setenv("PDT_BN_FOLD_MAX_COUT", limit)
+            eng = NativeResNet(get_spec("ResNet50", 10), device, hip, torch.bfloat16, hip_graphs=True)
+            eng.load_state_dict(state)
+            last4 = eng.spec.blocks[-1].units[-1]
+            assert eng._can_fold(last4, 1 << 30) == (on == "1" and limit == "0")
+            assert eng._can_fold(eng.spec.blocks[0].units[-1], 1 << 30) == (on == "1")
+            for _ in range(3):                               # eager, recorded, replayed
+                loss = float(eng.forward_backward(img, label))
+                torch.cuda.synchronize()
+                last = eng.params.g.clone()
+                eng.params.g.zero_()
+            losses.append(loss)
+            grads.append(last)
+    finally:
+        hip.set_deterministic(False)
+    assert losses[0] == losses[2] and losses[1] == losses[2], losses
     for key, e in eng.params.entries.items():
         a, b = grads[0][e.offset:e.offset + e.numel], grads[2][e.offset:e.offset + e.numel]
         assert torch.nn.functional.cosine_similarity(a, b, dim=0).item() > 0.99, key
@@ -440,7 +447,10 @@ def test_hip_engine_with_and_without_the_folded_path(hip, device, monkeypatch):
             eng.params.g.zero_()
         losses.append(loss)
         grads.append(last)
-    assert abs(losses[1] - losses[3]) < 1e-3 and abs(losses[2] - losses[3]) < 1e-3    # the forward pass is untouched
+    # the forward pass is untouched by the backward variants -- up to the last bit of the batch statistics, which float
+    # atomics leave open and which this randomly initialised network can amplify to 0.01-0.03 in the loss once in a
+    # while (the bit-exact form of this claim runs with ordered reductions in the test above)
+    assert abs(losses[1] - losses[3]) < 0.05 and abs(losses[2] - losses[3]) < 0.05
     # fused tails: bf16 roundings at other places of the forward pass; on 8 samples this randomly initialised network's
     # loss moves by +-0.03 when the input is scaled by one bf16 ulp (bench/diag/fwd_fuse_sensitivity.py), fused or not,
     # so only a gross error shows here -- the fused forward is held to 1 % of the fp32 loss on a conditioned network in
