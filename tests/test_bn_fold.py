@@ -433,24 +433,28 @@ def test_hip_engine_with_and_without_the_folded_path(hip, device, monkeypatch):
     grads, losses = [], []
     monkeypatch.setenv("PDT_BN_FOLD_MIN_MB", "0")        # fold every bottleneck block, however small its tensors
     monkeypatch.setenv("PDT_BN_FOLD_MAX_COUT", "0")      # ... and however wide
-    for on, product, fwd in (("1", "1", "1"), ("1", "1", "0"), ("1", "0", "0"), ("0", "0", "0")):
-        monkeypatch.setenv("PDT_BN_FOLD", on)
-        monkeypatch.setenv("PDT_BN_FOLD_PRODUCT", product)
-        monkeypatch.setenv("PDT_FWD_FUSE", fwd)
-        eng = NativeResNet(get_spec("ResNet50", 10), device, hip, torch.bfloat16, hip_graphs=True)
-        eng.load_state_dict(state)
-        assert eng._bn_fold == (on == "1") and eng._bn_fold_product == (product == "1") and eng._fwd_fuse == (fwd == "1")
-        for _ in range(3):                               # eager, recorded, replayed
-            loss = float(eng.forward_backward(img, label))
-            torch.cuda.synchronize()
-            last = eng.params.g.clone()
-            eng.params.g.zero_()
-        losses.append(loss)
-        grads.append(last)
-    # the forward pass is untouched by the backward variants -- up to the last bit of the batch statistics, which float
-    # atomics leave open and which this randomly initialised network can amplify to 0.01-0.03 in the loss once in a
-    # while (the bit-exact form of this claim runs with ordered reductions in the test above)
-    assert abs(losses[1] - losses[3]) < 0.05 and abs(losses[2] - losses[3]) < 0.05
+    # ordered reductions (see the test above): the variants are compared tensor by tensor on a randomly initialised
+    # network, where a last-bit difference of a batch statistic would otherwise flip roundings once in a while; the
+    # fast path with float atomics is held against fp32 on a conditioned network in tests/test_engine_oracle_gpu.py
+    hip.set_deterministic(True)
+    try:
+        for on, product, fwd in (("1", "1", "1"), ("1", "1", "0"), ("1", "0", "0"), ("0", "0", "0")):
+            monkeypatch.setenv("PDT_BN_FOLD", on)
+            monkeypatch.setenv("PDT_BN_FOLD_PRODUCT", product)
+            monkeypatch.setenv("PDT_FWD_FUSE", fwd)
+            eng = NativeResNet(get_spec("ResNet50", 10), device, hip, torch.bfloat16, hip_graphs=True)
+            eng.load_state_dict(state)
+            assert eng._bn_fold == (on == "1") and eng._bn_fold_product == (product == "1") and eng._fwd_fuse == (fwd == "1")
+            for _ in range(3):                               # eager, recorded, replayed
+                loss = float(eng.forward_backward(img, label))
+                torch.cuda.synchronize()
+                last = eng.params.g.clone()
+                eng.params.g.zero_()
+            losses.append(loss)
+            grads.append(last)
+    finally:
+        hip.set_deterministic(False)
+    assert losses[1] == losses[3] and losses[2] == losses[3], losses     # the forward pass is untouched by the backward variants
     # fused tails: bf16 roundings at other places of the forward pass; on 8 samples this randomly initialised network's
     # loss moves by +-0.03 when the input is scaled by one bf16 ulp (bench/diag/fwd_fuse_sensitivity.py), fused or not,
     # so only a gross error shows here -- the fused forward is held to 1 % of the fp32 loss on a conditioned network in
